@@ -1,0 +1,723 @@
+"""Oracle A -- big-integer model of the reference hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a CPU restatement, in plain Python integers, of the algorithms on the
+hot path of alex-ozdemir/bulletproofs (`ark-bp`): variable-base MSM and the classic
+Bulletproofs IPA prover/verifier over the Pasta curves.  It is the *checker*: only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import it.
+The product path (bulletproofs_amd + the HIP library) never does.
+
+PARITY UNPINNED: the reference holds no known-answer vectors for this path
+ and its Rust toolchain and arkworks dependencies are
+absent from this container, so nothing here was checked against an actual run of
+the reference.  What pins this model: (i) algebraic invariants the reference's own
+tests assert (IpaRelation::check src/relations/ipa.rs:134-146, verifier acceptance
+src/proofs/bp_iter.rs:176, the fold invariant src/proofs/bp_iter.rs:105-110,
+Pippenger == naive == Bos-Coster); (ii) public KATs for the primitives it rebuilds
+(RFC 7539 ChaCha20 block, hashlib's Blake2s); (iii) curve equations.  Behaviour of
+the third-party crates (ark-ff/ark-ec/ark-std 0.3.0, rand 0.8.4, rand_chacha 0.3.1,
+ark-marlin 0.3.0) is restated from their published algorithms [UPSTREAM-RECALLED].
+
+Reference lines followed are cited at each function as (ref: path:line).
+"""
+from __future__ import annotations
+
+import hashlib
+import struct
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+# ---------------------------------------------------------------------------
+# Fields and curves  (ref: analysis/pasta.sage:1-2 for the two moduli)
+# ---------------------------------------------------------------------------
+PALLAS_BASE = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+PALLAS_SCALAR = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+R256 = 1 << 256
+MASK64 = (1 << 64) - 1
+
+
+@dataclass(frozen=True)
+class Curve:
+    """Short Weierstrass y^2 = x^3 + 5 (a = 0) over Fq with prime order r."""
+
+    name: str
+    curve_id: int
+    q: int  # base field modulus
+    r: int  # scalar field modulus (group order, cofactor 1)
+    b: int = 5
+
+    # -- Montgomery helpers (ark-ff Fp256 keeps limbs*R^-1 = value, R = 2^256) --
+    def to_mont_q(self, v: int) -> int:
+        return v * R256 % self.q
+
+    def from_mont_q(self, m: int) -> int:
+        return m * pow(R256, -1, self.q) % self.q
+
+    def to_mont_r(self, v: int) -> int:
+        return v * R256 % self.r
+
+    def from_mont_r(self, m: int) -> int:
+        return m * pow(R256, -1, self.r) % self.r
+
+
+PALLAS = Curve("pallas", 0, PALLAS_BASE, PALLAS_SCALAR)
+VESTA = Curve("vesta", 1, PALLAS_SCALAR, PALLAS_BASE)
+CURVES = {"pallas": PALLAS, "vesta": VESTA, 0: PALLAS, 1: VESTA}
+
+# Affine points are (x, y) tuples of canonical ints; None is the point at infinity.
+Affine = Optional[Tuple[int, int]]
+# Jacobian points are (X, Y, Z); Z == 0 is infinity.
+Jac = Tuple[int, int, int]
+JAC_INF: Jac = (0, 1, 0)  # ark-ec GroupProjective::zero() = (0, 1, 0) [UPSTREAM-RECALLED]
+
+
+def is_on_curve(c: Curve, p: Affine) -> bool:
+    if p is None:
+        return True
+    x, y = p
+    return (y * y - x * x * x - c.b) % c.q == 0
+
+
+def aff_neg(c: Curve, p: Affine) -> Affine:
+    if p is None:
+        return None
+    return (p[0], (-p[1]) % c.q)
+
+
+def aff_add(c: Curve, p: Affine, s: Affine) -> Affine:
+    """Textbook affine group law (independent of any projective formula)."""
+    if p is None:
+        return s
+    if s is None:
+        return p
+    q = c.q
+    x1, y1 = p
+    x2, y2 = s
+    if x1 == x2:
+        if (y1 + y2) % q == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, q) % q
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, q) % q
+    x3 = (lam * lam - x1 - x2) % q
+    y3 = (lam * (x1 - x3) - y1) % q
+    return (x3, y3)
+
+
+def to_jac(p: Affine) -> Jac:
+    if p is None:
+        return JAC_INF
+    return (p[0], p[1], 1)
+
+
+def jac_to_affine(c: Curve, p: Jac) -> Affine:
+    X, Y, Z = p
+    if Z % c.q == 0:
+        return None
+    zi = pow(Z, -1, c.q)
+    zi2 = zi * zi % c.q
+    return (X * zi2 % c.q, Y * zi2 * zi % c.q)
+
+
+def jac_double(c: Curve, p: Jac) -> Jac:
+    """dbl-2009-l for a = 0 (what ark-ec's double_in_place uses [UPSTREAM-RECALLED])."""
+    q = c.q
+    X, Y, Z = p
+    if Z == 0:
+        return p
+    A = X * X % q
+    B = Y * Y % q
+    C = B * B % q
+    D = 2 * ((X + B) * (X + B) - A - C) % q
+    E = 3 * A % q
+    F = E * E % q
+    X3 = (F - 2 * D) % q
+    Y3 = (E * (D - X3) - 8 * C) % q
+    Z3 = 2 * Y * Z % q
+    return (X3, Y3, Z3)
+
+
+def jac_add(c: Curve, p: Jac, s: Jac) -> Jac:
+    """add-2007-bl with the zero / equal-point special cases."""
+    q = c.q
+    if p[2] == 0:
+        return s
+    if s[2] == 0:
+        return p
+    X1, Y1, Z1 = p
+    X2, Y2, Z2 = s
+    Z1Z1 = Z1 * Z1 % q
+    Z2Z2 = Z2 * Z2 % q
+    U1 = X1 * Z2Z2 % q
+    U2 = X2 * Z1Z1 % q
+    S1 = Y1 * Z2 * Z2Z2 % q
+    S2 = Y2 * Z1 * Z1Z1 % q
+    if U1 == U2:
+        if S1 == S2:
+            return jac_double(c, p)
+        return JAC_INF
+    H = (U2 - U1) % q
+    I = 4 * H * H % q
+    J = H * I % q
+    rr = 2 * (S2 - S1) % q
+    V = U1 * I % q
+    X3 = (rr * rr - J - 2 * V) % q
+    Y3 = (rr * (V - X3) - 2 * S1 * J) % q
+    Z3 = ((Z1 + Z2) * (Z1 + Z2) - Z1Z1 - Z2Z2) * H % q
+    return (X3, Y3, Z3)
+
+
+def jac_neg(c: Curve, p: Jac) -> Jac:
+    return (p[0], (-p[1]) % c.q, p[2])
+
+
+def jac_mul(c: Curve, p: Jac, k: int) -> Jac:
+    """MSB-first double-and-add over the canonical scalar (ark-ec Group::mul,
+    used by the naive msm at ref: src/util/msm.rs:21 and the folds at
+    ref: src/proofs/bp_iter.rs:99,103)."""
+    k %= c.r
+    acc = JAC_INF
+    for i in range(k.bit_length() - 1, -1, -1):
+        acc = jac_double(c, acc)
+        if (k >> i) & 1:
+            acc = jac_add(c, acc, p)
+    return acc
+
+
+def aff_mul(c: Curve, p: Affine, k: int) -> Affine:
+    return jac_to_affine(c, jac_mul(c, to_jac(p), k))
+
+
+def jac_eq(c: Curve, p: Jac, s: Jac) -> bool:
+    return jac_to_affine(c, p) == jac_to_affine(c, s)
+
+
+# ---------------------------------------------------------------------------
+# MSM  (ref: src/util/msm.rs)
+# ---------------------------------------------------------------------------
+def msm_naive(c: Curve, bases: Sequence[Jac], scalars: Sequence[int]) -> Jac:
+    """ref: src/util/msm.rs:13-24 -- zip truncates to the shorter input."""
+    acc = JAC_INF
+    for base, s in zip(bases, scalars):
+        acc = jac_add(c, acc, jac_mul(c, base, s))
+    return acc
+
+
+def ark_log2(x: int) -> int:
+    """ark_std::log2: ceil(log2(x)), 0 for x in {0, 1} [UPSTREAM-RECALLED]."""
+    if x <= 1:
+        return 0
+    return (x - 1).bit_length()
+
+
+def pippenger_window(size: int) -> int:
+    """ref: src/util/msm.rs:83-86,102-106."""
+    if size < 32:
+        return 3
+    return ark_log2(size) * 69 // 100 + 2
+
+
+def msm_pippenger(c: Curve, bases: Sequence[Jac], scalars: Sequence[int]) -> Jac:
+    """ref: src/util/msm.rs:88-193 (same window schedule, unsigned digits, zero-scalar
+    filter :100, scalar==1 shortcut :127-132, running-sum reduction :167-171,
+    high->low Horner :177-190)."""
+    pairs = list(zip(bases, [s % c.r for s in scalars]))
+    size = len(pairs)
+    live = [(b, s) for (b, s) in pairs if s != 0]
+    cbits = pippenger_window(size)
+    num_bits = c.r.bit_length()  # 255
+    window_sums: List[Jac] = []
+    for w_start in range(0, num_bits, cbits):
+        res = JAC_INF
+        buckets = [JAC_INF] * ((1 << cbits) - 1)
+        for base, s in live:
+            if s == 1:
+                if w_start == 0:
+                    res = jac_add(c, res, base)
+            else:
+                d = (s >> w_start) % (1 << cbits)
+                if d != 0:
+                    buckets[d - 1] = jac_add(c, buckets[d - 1], base)
+        running = JAC_INF
+        for bkt in reversed(buckets):
+            running = jac_add(c, running, bkt)
+            res = jac_add(c, res, running)
+        window_sums.append(res)
+    lowest = window_sums[0]
+    total = JAC_INF
+    for s_i in reversed(window_sums[1:]):
+        total = jac_add(c, total, s_i)
+        for _ in range(cbits):
+            total = jac_double(c, total)
+    return jac_add(c, lowest, total)
+
+
+def msm_bos_coster(c: Curve, bases: Sequence[Jac], scalars: Sequence[int]) -> Jac:
+    """ref: src/util/msm.rs:34-81 (max-heap keyed on the scalar only)."""
+    import heapq
+
+    heap: list = []
+    tie = 0
+    for b, s in zip(bases, scalars):
+        s %= c.r
+        if s != 0:
+            heap.append((-s, tie, b))
+            tie += 1
+    heapq.heapify(heap)
+    while len(heap) > 1:
+        fx, _, fg = heapq.heappop(heap)
+        sx, _, sg = heapq.heappop(heap)
+        fx, sx = -fx, -sx
+        if (fx >> 1) > sx:
+            tie += 1
+            heapq.heappush(heap, (-sx, tie, sg))
+            if fx & 1:
+                tie += 1
+                heapq.heappush(heap, (-1, tie, fg))
+            tie += 1
+            heapq.heappush(heap, (-(fx >> 1), tie, jac_double(c, fg)))
+        else:
+            fx -= sx
+            tie += 1
+            heapq.heappush(heap, (-sx, tie, jac_add(c, fg, sg)))
+            if fx != 0:
+                tie += 1
+                heapq.heappush(heap, (-fx, tie, fg))
+    if heap:
+        x, _, g = heap[0]
+        return jac_mul(c, g, -x)
+    return JAC_INF
+
+
+# ---------------------------------------------------------------------------
+# Vector utilities  (ref: src/util/mod.rs)
+# ---------------------------------------------------------------------------
+def ip(c: Curve, a: Sequence[int], b: Sequence[int]) -> int:
+    """ref: src/util/mod.rs:17-23 (asserts equal length)."""
+    assert len(a) == len(b)
+    return sum(x * y for x, y in zip(a, b)) % c.r
+
+
+def zero_pad_to_two_power(v: Sequence, zero):
+    """ref: src/util/mod.rs:137-144."""
+    out = list(v)
+    n = len(out)
+    want = 1 if n <= 1 else 1 << (n - 1).bit_length()
+    out.extend([zero] * (want - n))
+    return out
+
+
+def fold_scalars(c: Curve, v: Sequence[int], s_lo: int, s_hi: int) -> List[int]:
+    """out[i] = s_lo*v[i] + s_hi*v[i+n]  (ref: src/proofs/bp_iter.rs:88-95;
+    a uses (x, x^-1), b uses (x^-1, x))."""
+    n = len(v) // 2
+    return [(s_lo * v[i] + s_hi * v[i + n]) % c.r for i in range(n)]
+
+
+def fold_points(c: Curve, g: Sequence[Jac], s_lo: int, s_hi: int) -> List[Jac]:
+    """out[i] = g[i]*s_lo + g[i+n]*s_hi  (ref: src/proofs/bp_iter.rs:97-104;
+    A uses (x^-1, x), B uses (x, x^-1))."""
+    n = len(g) // 2
+    return [jac_add(c, jac_mul(c, g[i], s_lo), jac_mul(c, g[i + n], s_hi)) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------
+# ChaCha / rand_core BlockRng / ark_std::test_rng   [UPSTREAM-RECALLED]
+# ---------------------------------------------------------------------------
+def _rotl32(v: int, n: int) -> int:
+    return ((v << n) & 0xFFFFFFFF) | (v >> (32 - n))
+
+
+def chacha_block(key_words: Sequence[int], counter: int, stream: int, rounds: int) -> List[int]:
+    """One 64-byte ChaCha block with a 64-bit block counter (words 12,13) and a
+    64-bit stream id (words 14,15), as rand_chacha lays the state out."""
+    st = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574]
+    st += list(key_words)
+    st += [counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF, stream & 0xFFFFFFFF, (stream >> 32) & 0xFFFFFFFF]
+    x = list(st)
+
+    def qr(a, b, c_, d):
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF
+        x[d] = _rotl32(x[d] ^ x[a], 16)
+        x[c_] = (x[c_] + x[d]) & 0xFFFFFFFF
+        x[b] = _rotl32(x[b] ^ x[c_], 12)
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF
+        x[d] = _rotl32(x[d] ^ x[a], 8)
+        x[c_] = (x[c_] + x[d]) & 0xFFFFFFFF
+        x[b] = _rotl32(x[b] ^ x[c_], 7)
+
+    for _ in range(rounds // 2):
+        qr(0, 4, 8, 12)
+        qr(1, 5, 9, 13)
+        qr(2, 6, 10, 14)
+        qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15)
+        qr(1, 6, 11, 12)
+        qr(2, 7, 8, 13)
+        qr(3, 4, 9, 14)
+    return [(x[i] + st[i]) & 0xFFFFFFFF for i in range(16)]
+
+
+class ChaChaRng:
+    """rand_chacha ChaChaXRng behind rand_core::block::BlockRng: a 64-word buffer
+    (four blocks per refill), `next_u32` consumes one word, `next_u64` two
+    (low word first) with the straddle rule at the last buffer word."""
+
+    BUF_WORDS = 64
+
+    def __init__(self, seed: bytes, rounds: int):
+        assert len(seed) == 32
+        self.key = list(struct.unpack("<8I", seed))
+        self.rounds = rounds
+        self.counter = 0
+        self.stream = 0
+        self.buf: List[int] = [0] * self.BUF_WORDS
+        self.index = self.BUF_WORDS  # empty
+
+    def _generate(self) -> None:
+        out: List[int] = []
+        for i in range(4):
+            out += chacha_block(self.key, self.counter + i, self.stream, self.rounds)
+        self.counter += 4
+        self.buf = out
+
+    def next_u32(self) -> int:
+        if self.index >= self.BUF_WORDS:
+            self._generate()
+            self.index = 0
+        v = self.buf[self.index]
+        self.index += 1
+        return v
+
+    def next_u64(self) -> int:
+        n = self.BUF_WORDS
+        if self.index < n - 1:
+            lo, hi = self.buf[self.index], self.buf[self.index + 1]
+            self.index += 2
+        elif self.index >= n:
+            self._generate()
+            lo, hi = self.buf[0], self.buf[1]
+            self.index = 2
+        else:
+            lo = self.buf[n - 1]
+            self._generate()
+            hi = self.buf[0]
+            self.index = 1
+        return lo | (hi << 32)
+
+    # rand::Rng::gen::<bool>() = top bit of next_u32; gen::<u8>() = next_u32 as u8.
+    def gen_bool(self) -> bool:
+        return (self.next_u32() >> 31) == 1
+
+    def gen_bytes32(self) -> bytes:
+        """rng.gen::<[u8; 32]>() -- one next_u32 per byte (ref: src/lib.rs:117)."""
+        return bytes(self.next_u32() & 0xFF for _ in range(32))
+
+
+TEST_RNG_SEED = bytes(
+    [1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16
+)
+
+
+def test_rng() -> ChaChaRng:
+    """ark_std::test_rng(): StdRng (= ChaCha12) from a fixed seed (ref: src/lib.rs:111,
+    examples/msm_bench.rs:40)."""
+    return ChaChaRng(TEST_RNG_SEED, 12)
+
+
+def rand_field_mont(rng: ChaChaRng, modulus: int) -> int:
+    """ark-ff Fp256::rand: four next_u64 limbs, clear REPR_SHAVE_BITS = 1 top bit,
+    accept iff < modulus.  Returns the accepted limbs, which ARE the Montgomery
+    representation of the sampled element."""
+    while True:
+        limbs = [rng.next_u64() for _ in range(4)]
+        limbs[3] &= MASK64 >> 1
+        v = limbs[0] | (limbs[1] << 64) | (limbs[2] << 128) | (limbs[3] << 192)
+        if v < modulus:
+            return v
+
+
+def rand_scalar(c: Curve, rng: ChaChaRng) -> int:
+    """Fr::rand -> canonical value."""
+    return c.from_mont_r(rand_field_mont(rng, c.r))
+
+
+def sqrt_mod(a: int, p: int) -> Optional[int]:
+    """Tonelli-Shanks (either root; the caller applies the reference's sign rule)."""
+    a %= p
+    if a == 0:
+        return 0
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    s, t = 0, p - 1
+    while t % 2 == 0:
+        s += 1
+        t //= 2
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    m, cc, tt, r = s, pow(z, t, p), pow(a, t, p), pow(a, (t + 1) // 2, p)
+    while tt != 1:
+        i, t2 = 0, tt
+        while t2 != 1:
+            t2 = t2 * t2 % p
+            i += 1
+        b = pow(cc, 1 << (m - i - 1), p)
+        m, cc = i, b * b % p
+        tt, r = tt * cc % p, r * b % p
+    return r
+
+
+def rand_point(c: Curve, rng: ChaChaRng) -> Affine:
+    """ark-ec SW GroupProjective::rand: loop { x = Fq::rand; greatest = rng.gen::<bool>();
+    if x^3+b is a square: y = sqrt, negy = -y, take y if (y < negy) ^ greatest else negy }.
+    Cofactor is 1, so the result has Z = 1."""
+    while True:
+        x = c.from_mont_q(rand_field_mont(rng, c.q))
+        greatest = rng.gen_bool()
+        y = sqrt_mod((x * x * x + c.b) % c.q, c.q)
+        if y is None:
+            continue
+        negy = (-y) % c.q
+        return (x, y if ((y < negy) != greatest) else negy)
+
+
+def msm_bench_inputs(c: Curve, n: int) -> Tuple[List[Affine], List[int]]:
+    """ref: examples/msm_bench.rs:40-44 -- one test_rng stream: n points, then n scalars."""
+    rng = test_rng()
+    gs = [rand_point(c, rng) for _ in range(n)]
+    xs = [rand_scalar(c, rng) for _ in range(n)]
+    return gs, xs
+
+
+# ---------------------------------------------------------------------------
+# Fiat-Shamir  (ark-marlin 0.3 FiatShamirRng<Blake2s>)  (ref: src/lib.rs:5)
+# ---------------------------------------------------------------------------
+def fe_bytes(v: int) -> bytes:
+    """ark-ff ToBytes for Fp256: canonical value, 4 x u64 little-endian."""
+    return int(v).to_bytes(32, "little")
+
+
+def point_bytes_normalised(p: Affine) -> bytes:
+    """ToBytes for GroupProjective writes X || Y || Z.  Under the normalise-at-boundary
+    rule every group element entering the transcript is
+    (x, y, 1), and infinity is ark's zero() = (0, 1, 0)."""
+    if p is None:
+        return fe_bytes(0) + fe_bytes(1) + fe_bytes(0)
+    return fe_bytes(p[0]) + fe_bytes(p[1]) + fe_bytes(1)
+
+
+class FiatShamirRng:
+    def __init__(self, seed_bytes: bytes):
+        self.seed = hashlib.blake2s(seed_bytes).digest()
+        self.r = ChaChaRng(self.seed, 20)
+
+    def absorb(self, data: bytes) -> None:
+        self.seed = hashlib.blake2s(data + self.seed).digest()
+        self.r = ChaChaRng(self.seed, 20)
+
+    def rand_scalar(self, c: Curve) -> int:
+        return rand_scalar(c, self.r)
+
+
+# ---------------------------------------------------------------------------
+# IPA relation, prover, verifier, 2-ary step
+# ---------------------------------------------------------------------------
+@dataclass
+class IpaInstance:
+    a_gens: List[Affine]
+    b_gens: List[Affine]
+    ip_gen: Affine
+    result: Affine
+
+
+@dataclass
+class IpaWitness:
+    a: List[int]
+    b: List[int]
+
+
+def commit_for_witness(c: Curve, a_gens, b_gens, ip_gen, wit: IpaWitness) -> Affine:
+    """ref: src/relations/ipa.rs:37-41."""
+    t = msm_pippenger(c, [to_jac(g) for g in a_gens], wit.a)
+    t = jac_add(c, t, msm_pippenger(c, [to_jac(g) for g in b_gens], wit.b))
+    t = jac_add(c, t, jac_mul(c, to_jac(ip_gen), ip(c, wit.a, wit.b)))
+    return jac_to_affine(c, t)
+
+
+def sample_ipa(c: Curve, rng: ChaChaRng, length: int) -> Tuple[IpaInstance, IpaWitness]:
+    """ref: src/relations/ipa.rs:28-36,90-97,110-115 (sampling order a_gens, b_gens,
+    ip_gen, a, b)."""
+    a_gens = [rand_point(c, rng) for _ in range(length)]
+    b_gens = [rand_point(c, rng) for _ in range(length)]
+    ip_gen = rand_point(c, rng)
+    a = [rand_scalar(c, rng) for _ in range(length)]
+    b = [rand_scalar(c, rng) for _ in range(length)]
+    wit = IpaWitness(a, b)
+    return IpaInstance(a_gens, b_gens, ip_gen, commit_for_witness(c, a_gens, b_gens, ip_gen, wit)), wit
+
+
+def ipa_check(c: Curve, inst: IpaInstance, wit: IpaWitness) -> bool:
+    """ref: src/relations/ipa.rs:134-146."""
+    n = len(inst.a_gens)
+    if not (len(inst.b_gens) == n == len(wit.a) == len(wit.b)):
+        return False
+    return commit_for_witness(c, inst.a_gens, inst.b_gens, inst.ip_gen, wit) == inst.result
+
+
+@dataclass
+class BpProof:
+    ls: List[Affine]
+    rs: List[Affine]
+    final_a: int
+    final_b: int
+    challenges: List[int]  # not part of the reference's BpProof; kept for parity tests
+
+
+def bp_prove(c: Curve, inst: IpaInstance, wit: IpaWitness, fs: FiatShamirRng) -> BpProof:
+    """ref: src/proofs/bp_iter.rs:49-128, with every msm result normalised before it is
+    absorbed (normalise-at-boundary rule)."""
+    a = zero_pad_to_two_power(wit.a, 0)
+    b = zero_pad_to_two_power(wit.b, 0)
+    A = zero_pad_to_two_power([to_jac(g) for g in inst.a_gens], JAC_INF)
+    B = zero_pad_to_two_power([to_jac(g) for g in inst.b_gens], JAC_INF)
+    q = to_jac(inst.ip_gen)
+    ls, rs, challs = [], [], []
+    while len(a) > 1:
+        n = len(a) // 2
+        l = msm_pippenger(c, A[n:] + B[:n] + [q], a[:n] + b[n:] + [ip(c, a[:n], b[n:])])
+        r = msm_pippenger(c, A[:n] + B[n:] + [q], a[n:] + b[:n] + [ip(c, a[n:], b[:n])])
+        l_aff, r_aff = jac_to_affine(c, l), jac_to_affine(c, r)
+        ls.append(l_aff)
+        rs.append(r_aff)
+        fs.absorb(point_bytes_normalised(l_aff))
+        fs.absorb(point_bytes_normalised(r_aff))
+        x = fs.rand_scalar(c)
+        x_inv = pow(x, -1, c.r)
+        challs.append(x)
+        a = fold_scalars(c, a, x, x_inv)
+        b = fold_scalars(c, b, x_inv, x)
+        A = fold_points(c, A, x_inv, x)
+        B = fold_points(c, B, x, x_inv)
+    return BpProof(ls, rs, a[0], b[0], challs)
+
+
+def scalars_from_challenges(c: Curve, challs: Sequence[int]) -> List[int]:
+    """ref: src/proofs/bp_iter.rs:25-42."""
+    if len(challs) == 0:
+        return [1]
+    left = scalars_from_challenges(c, challs[1:])
+    n = len(left)
+    ch = challs[0]
+    ch_inv = pow(ch, -1, c.r)
+    for i in range(n):
+        left.append(left[i] * ch % c.r)
+        left[i] = left[i] * ch_inv % c.r
+    return left
+
+
+def bp_verify(c: Curve, inst: IpaInstance, proof: BpProof, fs: FiatShamirRng) -> bool:
+    """ref: src/proofs/bp_iter.rs:130-178."""
+    A = zero_pad_to_two_power([to_jac(g) for g in inst.a_gens], JAC_INF)
+    B = zero_pad_to_two_power([to_jac(g) for g in inst.b_gens], JAC_INF)
+    challs = []
+    for l, r in zip(proof.ls, proof.rs):
+        fs.absorb(point_bytes_normalised(l))
+        fs.absorb(point_bytes_normalised(r))
+        challs.append(fs.rand_scalar(c))
+    challs_inv = [pow(x, -1, c.r) for x in challs]
+    s = scalars_from_challenges(c, challs)
+    s_inv = scalars_from_challenges(c, challs_inv)
+    pts = list(A)
+    scs = [v * proof.final_a % c.r for v in s]
+    pts += B
+    scs += [v * proof.final_b % c.r for v in s_inv]
+    pts.append(to_jac(inst.ip_gen))
+    scs.append(proof.final_a * proof.final_b % c.r)
+    for j in range(len(proof.ls)):
+        pts.append(to_jac(proof.ls[j]))
+        scs.append((-challs[j] * challs[j]) % c.r)
+        pts.append(to_jac(proof.rs[j]))
+        scs.append((-challs_inv[j] * challs_inv[j]) % c.r)
+    return jac_to_affine(c, msm_pippenger(c, pts, scs)) == inst.result
+
+
+def bp_2ary_step_prove(c: Curve, inst: IpaInstance, wit: IpaWitness, fs: FiatShamirRng):
+    """ref: src/reductions/bp_2ary_step.rs:24-87 -> ((L, R), next instance, next witness)."""
+    a = zero_pad_to_two_power(wit.a, 0)
+    b = zero_pad_to_two_power(wit.b, 0)
+    A = zero_pad_to_two_power([to_jac(g) for g in inst.a_gens], JAC_INF)
+    B = zero_pad_to_two_power([to_jac(g) for g in inst.b_gens], JAC_INF)
+    p = to_jac(inst.result)
+    q = to_jac(inst.ip_gen)
+    assert len(a) % 2 == 0
+    n = len(a) // 2
+    l = jac_add(c, jac_add(c, msm_pippenger(c, A[n:], a[:n]), msm_pippenger(c, B[:n], b[n:])),
+                jac_mul(c, q, ip(c, a[:n], b[n:])))
+    r = jac_add(c, jac_add(c, msm_pippenger(c, A[:n], a[n:]), msm_pippenger(c, B[n:], b[:n])),
+                jac_mul(c, q, ip(c, a[n:], b[:n])))
+    l_aff, r_aff = jac_to_affine(c, l), jac_to_affine(c, r)
+    fs.absorb(point_bytes_normalised(l_aff))
+    fs.absorb(point_bytes_normalised(r_aff))
+    x = fs.rand_scalar(c)
+    x_inv = pow(x, -1, c.r)
+    a2 = fold_scalars(c, a, x, x_inv)
+    b2 = fold_scalars(c, b, x_inv, x)
+    p2 = jac_add(c, jac_add(c, jac_mul(c, to_jac(l_aff), x * x % c.r),
+                            jac_mul(c, to_jac(r_aff), x_inv * x_inv % c.r)), p)
+    A2 = [jac_to_affine(c, g) for g in fold_points(c, A, x_inv, x)]
+    B2 = [jac_to_affine(c, g) for g in fold_points(c, B, x, x_inv)]
+    inst2 = IpaInstance(A2, B2, inst.ip_gen, jac_to_affine(c, p2))
+    return (l_aff, r_aff), inst2, IpaWitness(a2, b2), x
+
+
+def bp_2ary_step_verify(c: Curve, inst: IpaInstance, proof, fs: FiatShamirRng) -> IpaInstance:
+    """ref: src/reductions/bp_2ary_step.rs:88-125."""
+    l_aff, r_aff = proof
+    A = zero_pad_to_two_power([to_jac(g) for g in inst.a_gens], JAC_INF)
+    B = zero_pad_to_two_power([to_jac(g) for g in inst.b_gens], JAC_INF)
+    fs.absorb(point_bytes_normalised(l_aff))
+    fs.absorb(point_bytes_normalised(r_aff))
+    x = fs.rand_scalar(c)
+    x_inv = pow(x, -1, c.r)
+    p2 = jac_add(c, jac_add(c, jac_mul(c, to_jac(l_aff), x * x % c.r),
+                            jac_mul(c, to_jac(r_aff), x_inv * x_inv % c.r)), to_jac(inst.result))
+    A2 = [jac_to_affine(c, g) for g in fold_points(c, A, x_inv, x)]
+    B2 = [jac_to_affine(c, g) for g in fold_points(c, B, x, x_inv)]
+    return IpaInstance(A2, B2, inst.ip_gen, jac_to_affine(c, p2))
+
+
+# ---------------------------------------------------------------------------
+# Byte encodings shared by the golden fixtures and the C-ABI tests
+# ---------------------------------------------------------------------------
+def mont_limbs_bytes(v_mont: int) -> bytes:
+    return int(v_mont).to_bytes(32, "little")
+
+
+def scalar_to_abi(c: Curve, s: int) -> bytes:
+    """Canonical scalar -> 32 B Montgomery limbs (what ark's Fr holds in memory)."""
+    return mont_limbs_bytes(c.to_mont_r(s % c.r))
+
+
+def scalar_from_abi(c: Curve, b: bytes) -> int:
+    return c.from_mont_r(int.from_bytes(b, "little"))
+
+
+def point_to_abi_jac(c: Curve, p: Jac) -> bytes:
+    """Jacobian (X, Y, Z) canonical -> 96 B Montgomery limbs."""
+    return b"".join(mont_limbs_bytes(c.to_mont_q(v % c.q)) for v in p)
+
+
+def point_to_abi_affine(c: Curve, p: Affine) -> bytes:
+    """Affine -> 64 B Montgomery limbs; infinity is encoded as (0, 0), which is not
+    on y^2 = x^3 + 5."""
+    if p is None:
+        return bytes(64)
+    return mont_limbs_bytes(c.to_mont_q(p[0])) + mont_limbs_bytes(c.to_mont_q(p[1]))
+
+
+def point_from_abi_affine(c: Curve, b: bytes) -> Affine:
+    x = int.from_bytes(b[:32], "little")
+    y = int.from_bytes(b[32:64], "little")
+    if x == 0 and y == 0:
+        return None
+    return (c.from_mont_q(x), c.from_mont_q(y))
