@@ -1,0 +1,27 @@
+# Builds the three native artefacts:
+#   bulletproofs_amd/lib/libbpgpu.so   the product: HIP kernels + C ABI (include/bpgpu.h), gfx950
+#   bulletproofs_amd/lib/libbpchk.so   test-only host build of the device arithmetic headers
+#   oracle/_build/libpasta_oracle.so   test-only CPU restatement of the reference algorithms (Oracle B)
+HIPCC ?= hipcc
+CXX ?= g++
+CC ?= gcc
+CSRC := bulletproofs_amd/csrc
+LIBDIR := bulletproofs_amd/lib
+
+all: $(LIBDIR)/libbpgpu.so $(LIBDIR)/libbpchk.so oracle/_build/libpasta_oracle.so
+
+$(LIBDIR)/libbpgpu.so: $(CSRC)/bpgpu.hip $(CSRC)/kernels.cuh $(CSRC)/curve.cuh $(CSRC)/field.cuh $(CSRC)/host_field.h $(CSRC)/pasta_consts.h include/bpgpu.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC $(HIPFLAGS) $< -o $@
+
+$(LIBDIR)/libbpchk.so: $(CSRC)/host_check.cpp $(CSRC)/curve.cuh $(CSRC)/field.cuh $(CSRC)/pasta_consts.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) -O2 -std=c++17 -DBP_CHECKED -shared -fPIC -x c++ $< -o $@
+
+oracle/_build/libpasta_oracle.so: oracle/pasta_oracle.c
+	@mkdir -p oracle/_build
+	$(CC) -O3 -march=native -std=c11 -shared -fPIC -pthread $< -o $@
+
+clean:
+	rm -f $(LIBDIR)/*.so oracle/_build/*.so
+.PHONY: all clean

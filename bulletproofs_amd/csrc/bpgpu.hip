@@ -1,0 +1,853 @@
+// C ABI of the MI355X backend (include/bpgpu.h).  Host orchestration of the kernels in
+// kernels.cuh plus the short serial tails (Horner combine over window sums,
+// normalisation, joint-sparse-form recoding) in host_field.h.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bpgpu.h"
+#include "host_field.h"
+#include "kernels.cuh"
+
+using namespace bpgpu;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(BPGPU_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define TRY(expr)          \
+  do {                     \
+    int r_ = (expr);       \
+    if (r_ != 0) return r_; \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct Ctx {
+  bool ready = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  int window_bits = 0;
+  float msm_ms[8] = {};
+  // MSM workspace (grow-only)
+  DevBuf counts, offs, cursor, sorted, bsum, partial, winsum;
+  // staging for host-buffer entry points
+  DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
+  std::vector<uint32_t> h_winsum;
+};
+
+Ctx g_ctx;
+std::mutex g_mu;
+
+inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+int check_ready() {
+  if (!g_ctx.ready) return fail(BPGPU_E_NOINIT, "bpgpu_init has not been called");
+  HIP_TRY(hipSetDevice(g_ctx.device));  // the current device is per host thread
+  return 0;
+}
+int check_curve(int curve) {
+  if (curve != BPGPU_PALLAS && curve != BPGPU_VESTA) return fail(BPGPU_E_ARG, "unknown curve id %d", curve);
+  return 0;
+}
+
+// ---- host tail helpers ------------------------------------------------------
+template <int BF>
+host::HPoint<BF> hpoint_from_words(const uint32_t* w) {
+  host::HPoint<BF> p;
+  memcpy(p.x.v, w, 32);
+  memcpy(p.y.v, w + 8, 32);
+  memcpy(p.zz.v, w + 16, 32);
+  memcpy(p.zzz.v, w + 24, 32);
+  p.inf = host::HF<BF>::is_zero(p.zz);
+  return p;
+}
+
+template <int BF>
+void write_xy_inf(const host::HPoint<BF>& p, uint64_t out[9]) {
+  host::H4 x, y;
+  bool finite = host::HEc<BF>::to_affine(p, x, y);
+  memcpy(out, x.v, 32);
+  memcpy(out + 4, y.v, 32);
+  out[8] = finite ? 0 : 1;
+}
+
+// Horner combine, high window to low with c doublings per step (msm.rs:177-190)
+template <int BF>
+host::HPoint<BF> horner(const uint32_t* winsums, int W, int c) {
+  using E = host::HEc<BF>;
+  host::HPoint<BF> total = E::identity();
+  for (int j = W - 1; j >= 0; j--) {
+    if (j != W - 1)
+      for (int k = 0; k < c; k++) total = E::dbl(total);
+    total = E::add(total, hpoint_from_words<BF>(winsums + 32 * j));
+  }
+  return total;
+}
+
+int choose_window(uint32_t n) {
+  if (g_ctx.window_bits) return g_ctx.window_bits;
+  int lg = 0;
+  while ((1ull << (lg + 1)) <= n) lg++;
+  int c = lg - 4;
+  if (c < 2) c = 2;
+  if (c > 16) c = 16;
+  return c;
+}
+
+// Batched MSM over device-resident operands.  d_points: dev affine; d_scalars: ark form.
+// out[m] receives xy_inf.
+template <int CURVE>
+int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, uint64_t (*out)[9]) {
+  constexpr int BF = CURVE, SF = 1 - CURVE;
+  Ctx& C = g_ctx;
+  for (int m = 0; m < plan.M; m++) {
+    memset(out[m], 0, 72);
+    out[m][8] = 1;
+  }
+  if (plan.n == 0) return 0;
+  const int c = choose_window(plan.n);
+  const int W = (256 + c - 1) / c;
+  plan.c = c;
+  plan.W = W;
+  const uint32_t B = 1u << (c - 1);
+  const uint32_t NB = (uint32_t)plan.M * W * B;
+  const uint64_t slots = (uint64_t)plan.M * plan.n;
+  // run length for the bucket reduction: aim at >= 64k lanes
+  int s = 0;
+  while ((NB >> s) > 65536u && s < c - 1) s++;
+  const uint32_t nruns = NB >> s;
+  const uint32_t runs_per_window = B >> s;
+
+  TRY(C.counts.ensure((size_t)(NB + 1) * 4));
+  TRY(C.offs.ensure((size_t)(NB + 1) * 4));
+  TRY(C.cursor.ensure((size_t)(NB + 1) * 4));
+  TRY(C.sorted.ensure((size_t)slots * W * 4 + 4));
+  TRY(C.bsum.ensure((size_t)NB * 128));
+  TRY(C.partial.ensure((size_t)nruns * 128));
+  TRY(C.winsum.ensure((size_t)plan.M * W * 128));
+
+  hipStream_t st = C.stream;
+  HIP_TRY(hipEventRecord(C.ev[0], st));
+  HIP_TRY(hipMemsetAsync(C.counts.p, 0, (size_t)(NB + 1) * 4, st));
+  k_digits<SF, 0><<<cdiv(slots, 256), 256, 0, st>>>(plan, d_scalars, C.counts.as<uint32_t>(), nullptr);
+  HIP_TRY(hipEventRecord(C.ev[1], st));
+  k_scan<<<1, 1024, 0, st>>>(C.counts.as<uint32_t>(), C.offs.as<uint32_t>(), C.cursor.as<uint32_t>(), NB);
+  HIP_TRY(hipEventRecord(C.ev[2], st));
+  k_digits<SF, 1><<<cdiv(slots, 256), 256, 0, st>>>(plan, d_scalars, C.cursor.as<uint32_t>(),
+                                                       C.sorted.as<uint32_t>());
+  HIP_TRY(hipEventRecord(C.ev[3], st));
+  k_accum<BF><<<cdiv(NB, 128), 128, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
+                                             C.bsum.as<uint32_t>(), NB);
+  HIP_TRY(hipEventRecord(C.ev[4], st));
+  k_reduce1<BF><<<cdiv(nruns, 64), 64, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s, c - 1);
+  k_reduce2<BF><<<plan.M * W, 256, 0, st>>>(C.partial.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window);
+  HIP_TRY(hipEventRecord(C.ev[5], st));
+  C.h_winsum.resize((size_t)plan.M * W * 32);
+  HIP_TRY(hipMemcpyAsync(C.h_winsum.data(), C.winsum.p, (size_t)plan.M * W * 128, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  auto t0 = std::chrono::steady_clock::now();
+  for (int m = 0; m < plan.M; m++) {
+    host::HPoint<BF> r = horner<BF>(C.h_winsum.data() + (size_t)m * W * 32, W, c);
+    write_xy_inf<BF>(r, out[m]);
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  float ms;
+  HIP_TRY(hipEventElapsedTime(&ms, C.ev[0], C.ev[1]));
+  C.msm_ms[0] = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, C.ev[1], C.ev[2]));
+  C.msm_ms[1] = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, C.ev[2], C.ev[3]));
+  C.msm_ms[2] = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, C.ev[3], C.ev[4]));
+  C.msm_ms[3] = ms;
+  C.msm_ms[4] = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, C.ev[4], C.ev[5]));
+  C.msm_ms[5] = ms;
+  C.msm_ms[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  HIP_TRY(hipEventElapsedTime(&ms, C.ev[0], C.ev[5]));
+  C.msm_ms[7] = ms;
+  return 0;
+}
+
+int msm_dispatch(int curve, const uint32_t* d_points, const uint32_t* d_scalars, const MsmPlan& plan,
+                 uint64_t (*out)[9]) {
+  return curve == BPGPU_PALLAS ? msm_core<0>(d_points, d_scalars, plan, out)
+                               : msm_core<1>(d_points, d_scalars, plan, out);
+}
+
+MsmPlan single_plan(uint32_t n) {
+  MsmPlan p;
+  memset(&p, 0, sizeof p);
+  p.M = 1;
+  p.n = n;
+  p.seg[0][0] = MsmSeg{0, 0, n};
+  return p;
+}
+
+int points_in(int curve, const uint32_t* d_in, uint32_t* d_out, size_t n, int fmt) {
+  if (n == 0) return 0;
+  if (curve == BPGPU_PALLAS)
+    k_points_in<0><<<cdiv(n, 64), 64, 0, g_ctx.stream>>>(d_in, d_out, (uint32_t)n, fmt);
+  else
+    k_points_in<1><<<cdiv(n, 64), 64, 0, g_ctx.stream>>>(d_in, d_out, (uint32_t)n, fmt);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int points_out(int curve, const uint32_t* d_in, uint32_t* d_out, size_t n) {
+  if (n == 0) return 0;
+  if (curve == BPGPU_PALLAS)
+    k_points_out<0><<<cdiv(n, 256), 256, 0, g_ctx.stream>>>(d_in, d_out, (uint32_t)n);
+  else
+    k_points_out<1><<<cdiv(n, 256), 256, 0, g_ctx.stream>>>(d_in, d_out, (uint32_t)n);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// <a, b> for up to two pairs at once; results (ark form) land in d_out0 / d_out1.
+int ip_launch(int curve, const uint32_t* d_sc, IpPair p0, IpPair p1, int npairs, uint32_t n, uint32_t* d_out0,
+              uint32_t* d_out1) {
+  Ctx& C = g_ctx;
+  uint32_t nblk = n == 0 ? 1 : cdiv(n, 256 * 8);
+  if (nblk > 1024) nblk = 1024;
+  TRY(C.st_ip.ensure((size_t)2 * nblk * 32));
+  dim3 grid(nblk, npairs);
+  if (curve == BPGPU_PALLAS) {
+    k_ip_partial<1><<<grid, 256, 0, C.stream>>>(d_sc, p0, p1, n, C.st_ip.as<uint32_t>());
+    k_ip_final<1><<<npairs, 64, 0, C.stream>>>(C.st_ip.as<uint32_t>(), nblk, d_out0, d_out1);
+  } else {
+    k_ip_partial<0><<<grid, 256, 0, C.stream>>>(d_sc, p0, p1, n, C.st_ip.as<uint32_t>());
+    k_ip_final<0><<<npairs, 64, 0, C.stream>>>(C.st_ip.as<uint32_t>(), nblk, d_out0, d_out1);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+FoldScalars make_fold_scalars(const uint64_t lo[4], const uint64_t hi[4]) {
+  FoldScalars f;
+  memcpy(f.lo, lo, 32);
+  memcpy(f.hi, hi, 32);
+  return f;
+}
+
+int fold_scalars_launch(int curve, uint32_t* v0, uint32_t* o0, const FoldScalars& s0, uint32_t* v1, uint32_t* o1,
+                        const FoldScalars& s1, int nvec, uint32_t n) {
+  if (n == 0) return 0;
+  dim3 grid(cdiv(n, 256), nvec);
+  if (curve == BPGPU_PALLAS)
+    k_fold_scalars<1><<<grid, 256, 0, g_ctx.stream>>>(v0, o0, s0, v1, o1, s1, n);
+  else
+    k_fold_scalars<0><<<grid, 256, 0, g_ctx.stream>>>(v0, o0, s0, v1, o1, s1, n);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Joint sparse form (Solinas) of two canonical 256-bit scalars, as 4-bit codes.
+void shr1(uint64_t v[5]) {
+  for (int i = 0; i < 4; i++) v[i] = (v[i] >> 1) | (v[i + 1] << 63);
+  v[4] >>= 1;
+}
+bool nonzero(const uint64_t v[5]) { return (v[0] | v[1] | v[2] | v[3] | v[4]) != 0; }
+
+template <int SF>
+FoldPlan make_fold_plan(const uint64_t s_lo_ark[4], const uint64_t s_hi_ark[4]) {
+  using HFs = host::HF<SF>;
+  host::H4 a, b;
+  memcpy(a.v, s_lo_ark, 32);
+  memcpy(b.v, s_hi_ark, 32);
+  host::H4 ca = HFs::to_canon(a), cb = HFs::to_canon(b);
+  FoldPlan f;
+  memset(&f, 0, sizeof f);
+  memcpy(f.s_lo, ca.v, 32);
+  memcpy(f.s_hi, cb.v, 32);
+  uint64_t k0[5] = {ca.v[0], ca.v[1], ca.v[2], ca.v[3], 0};
+  uint64_t k1[5] = {cb.v[0], cb.v[1], cb.v[2], cb.v[3], 0};
+  int d0 = 0, d1 = 0, pos = 0;
+  while (nonzero(k0) || nonzero(k1) || d0 || d1) {
+    // l_i = d_i + k_i; only the low 3 bits matter
+    int l0 = (int)((k0[0] & 7) + d0) & 7, l1 = (int)((k1[0] & 7) + d1) & 7;
+    int u0 = 0, u1 = 0;
+    if (l0 & 1) {
+      u0 = 2 - (l0 & 3);
+      if (((l0 & 7) == 3 || (l0 & 7) == 5) && (l1 & 3) == 2) u0 = -u0;
+    }
+    if (l1 & 1) {
+      u1 = 2 - (l1 & 3);
+      if (((l1 & 7) == 3 || (l1 & 7) == 5) && (l0 & 3) == 2) u1 = -u1;
+    }
+    if (2 * d0 == 1 + u0) d0 = 1 - d0;
+    if (2 * d1 == 1 + u1) d1 = 1 - d1;
+    shr1(k0);
+    shr1(k1);
+    uint32_t code = 0;
+    if (u0 != 0 && u1 == 0) code = 1 | (u0 < 0 ? 8 : 0);
+    else if (u0 == 0 && u1 != 0) code = 2 | (u1 < 0 ? 8 : 0);
+    else if (u0 != 0 && u0 == u1) code = 3 | (u0 < 0 ? 8 : 0);
+    else if (u0 != 0) code = 4 | (u0 < 0 ? 8 : 0);  // u1 = -u0:  u0 (P - Q)
+    f.codes[pos >> 3] |= code << ((pos & 7) * 4);
+    pos++;
+  }
+  f.len = pos;
+  return f;
+}
+
+int fold_points_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64_t lo0[4], const uint64_t hi0[4],
+                       const uint32_t* g1, uint32_t* o1, const uint64_t lo1[4], const uint64_t hi1[4], int nvec,
+                       uint32_t n) {
+  if (n == 0) return 0;
+  dim3 grid(cdiv(n, 64), nvec);
+  if (curve == BPGPU_PALLAS) {
+    FoldPlan f0 = make_fold_plan<1>(lo0, hi0);
+    FoldPlan f1 = nvec > 1 ? make_fold_plan<1>(lo1, hi1) : f0;
+    k_fold_points<0><<<grid, 64, 0, g_ctx.stream>>>(g0, o0, f0, g1, o1, f1, n);
+  } else {
+    FoldPlan f0 = make_fold_plan<0>(lo0, hi0);
+    FoldPlan f1 = nvec > 1 ? make_fold_plan<0>(lo1, hi1) : f0;
+    k_fold_points<1><<<grid, 64, 0, g_ctx.stream>>>(g0, o0, f0, g1, o1, f1, n);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+size_t pow2_at_least(size_t n) {
+  size_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+struct bpgpu_ipa {
+  int curve;
+  size_t np;   // padded original length
+  size_t len;  // current vector length
+  // points: A at [0, np), B at [np, 2np), Q at 2np           (dev affine, 64 B each)
+  // scalars: a at [0, np), b at [np, 2np), c_L at 2np, c_R at 2np+1 (ark form, 32 B each)
+  uint32_t* d_pts;
+  uint32_t* d_sc;
+  bool lr_done;
+};
+
+extern "C" {
+
+const char* bpgpu_last_error(void) { return g_err.c_str(); }
+
+int bpgpu_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_ctx.ready) {
+    if (g_ctx.device != device) return fail(BPGPU_E_ARG, "already initialised on device %d", g_ctx.device);
+    return 0;
+  }
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) return fail(BPGPU_E_ARG, "device %d out of range (%d visible)", device, count);
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  for (auto& e : g_ctx.ev) HIP_TRY(hipEventCreate(&e));
+  g_ctx.device = device;
+  g_ctx.ready = true;
+  return 0;
+}
+
+void bpgpu_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx.ready) return;
+  (void)hipSetDevice(g_ctx.device);
+  (void)hipStreamSynchronize(g_ctx.stream);
+  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.cursor, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial,
+                    &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip})
+    b->release();
+  for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(g_ctx.stream);
+  g_ctx.ready = false;
+}
+
+int bpgpu_set_window_bits(int c) {
+  if (c != 0 && (c < 2 || c > 20)) return fail(BPGPU_E_ARG, "window bits %d outside [2, 20]", c);
+  g_ctx.window_bits = c;
+  return 0;
+}
+
+int bpgpu_dev_alloc(size_t bytes, void** dptr) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (!dptr) return fail(BPGPU_E_ARG, "null output pointer");
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+  return 0;
+}
+int bpgpu_dev_free(void* dptr) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipFree(dptr));
+  return 0;
+}
+int bpgpu_dev_upload(void* dptr, const void* host, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+int bpgpu_dev_download(void* host, const void* dptr, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_points_to_device(int curve, const uint64_t* points, size_t n, int fmt, void* d_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (fmt != 0 && fmt != 1) return fail(BPGPU_E_ARG, "fmt must be 0 (jacobian) or 1 (affine)");
+  if (n == 0) return 0;
+  if (!points || !d_out) return fail(BPGPU_E_ARG, "null pointer");
+  size_t bytes = n * (fmt == 0 ? 96 : 64);
+  TRY(g_ctx.st_pts_in.ensure(bytes));
+  HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, points, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), (uint32_t*)d_out, n, fmt));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_points_from_device(int curve, const void* d_points, size_t n, uint64_t* out_xyz) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (n == 0) return 0;
+  if (!d_points || !out_xyz) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(g_ctx.st_out.ensure(n * 96));
+  TRY(points_out(curve, (const uint32_t*)d_points, g_ctx.st_out.as<uint32_t>(), n));
+  HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_out.p, n * 96, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_msm_device(int curve, const void* d_points, const void* d_scalars, size_t n, uint64_t out_xy_inf[9]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!out_xy_inf) return fail(BPGPU_E_ARG, "null output");
+  if (n > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n && (!d_points || !d_scalars)) return fail(BPGPU_E_ARG, "null pointer");
+  return msm_dispatch(curve, (const uint32_t*)d_points, (const uint32_t*)d_scalars, single_plan((uint32_t)n),
+                      (uint64_t(*)[9])out_xy_inf);
+}
+
+static int msm_host(int curve, const uint64_t* points, int fmt, const uint64_t* scalars, size_t n,
+                    uint64_t out_xy_inf[9]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!out_xy_inf) return fail(BPGPU_E_ARG, "null output");
+  if (n > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n && (!points || !scalars)) return fail(BPGPU_E_ARG, "null pointer");
+  if (n) {
+    size_t pbytes = n * (fmt == 0 ? 96 : 64);
+    TRY(g_ctx.st_pts_in.ensure(pbytes));
+    TRY(g_ctx.st_pts.ensure(n * 64));
+    TRY(g_ctx.st_sc.ensure(n * 32));
+    HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, points, pbytes, hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+    TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), g_ctx.st_pts.as<uint32_t>(), n, fmt));
+  }
+  return msm_dispatch(curve, g_ctx.st_pts.as<uint32_t>(), g_ctx.st_sc.as<uint32_t>(), single_plan((uint32_t)n),
+                      (uint64_t(*)[9])out_xy_inf);
+}
+
+int bpgpu_msm(int curve, const uint64_t* points_xyz, const uint64_t* scalars, size_t n, uint64_t out_xy_inf[9]) {
+  return msm_host(curve, points_xyz, 0, scalars, n, out_xy_inf);
+}
+int bpgpu_msm_affine(int curve, const uint64_t* points_xy, const uint64_t* scalars, size_t n,
+                     uint64_t out_xy_inf[9]) {
+  return msm_host(curve, points_xy, 1, scalars, n, out_xy_inf);
+}
+
+int bpgpu_ip_device(int curve, const void* d_a, const void* d_b, size_t n, uint64_t out[4]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!out) return fail(BPGPU_E_ARG, "null output");
+  if (n > 0xffffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n && (!d_a || !d_b)) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(g_ctx.st_out.ensure(64));
+  // element offsets are relative to d_a; b is addressed through a second base by pointer difference
+  const uint32_t* base = (const uint32_t*)d_a;
+  ptrdiff_t diff = ((const uint8_t*)d_b - (const uint8_t*)d_a);
+  if (diff % 32 != 0 || diff / 32 < 0 || diff / 32 > 0xffffffffll) {
+    // unrelated allocations: stage b next to a copy of a
+    TRY(g_ctx.st_sc.ensure(2 * n * 32 + 32));
+    HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, d_a, n * 32, hipMemcpyDeviceToDevice, g_ctx.stream));
+    HIP_TRY(hipMemcpyAsync((uint8_t*)g_ctx.st_sc.p + n * 32, d_b, n * 32, hipMemcpyDeviceToDevice, g_ctx.stream));
+    base = g_ctx.st_sc.as<uint32_t>();
+    diff = (ptrdiff_t)n * 32;
+  }
+  IpPair p0{0u, (uint32_t)(diff / 32)};
+  TRY(ip_launch(curve, base, p0, p0, 1, (uint32_t)n, g_ctx.st_out.as<uint32_t>(), g_ctx.st_out.as<uint32_t>() + 8));
+  HIP_TRY(hipMemcpyAsync(out, g_ctx.st_out.p, 32, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_ip(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    TRY(check_ready());
+    TRY(check_curve(curve));
+    if (!out) return fail(BPGPU_E_ARG, "null output");
+    if (n > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
+    if (n && (!a || !b)) return fail(BPGPU_E_ARG, "null pointer");
+    TRY(g_ctx.st_sc.ensure(2 * n * 32 + 32));
+    TRY(g_ctx.st_out.ensure(64));
+    if (n) {
+      HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, a, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+      HIP_TRY(hipMemcpyAsync((uint8_t*)g_ctx.st_sc.p + n * 32, b, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+    }
+    IpPair p0{0u, (uint32_t)n};
+    TRY(ip_launch(curve, g_ctx.st_sc.as<uint32_t>(), p0, p0, 1, (uint32_t)n, g_ctx.st_out.as<uint32_t>(),
+                  g_ctx.st_out.as<uint32_t>() + 8));
+    HIP_TRY(hipMemcpyAsync(out, g_ctx.st_out.p, 32, hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  }
+  return 0;
+}
+
+int bpgpu_fold_scalars_device(int curve, const void* d_v, size_t n_out, const uint64_t s_lo[4],
+                              const uint64_t s_hi[4], void* d_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (n_out > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n_out && (!d_v || !d_out || !s_lo || !s_hi)) return fail(BPGPU_E_ARG, "null pointer");
+  FoldScalars f = make_fold_scalars(s_lo, s_hi);
+  TRY(fold_scalars_launch(curve, (uint32_t*)d_v, (uint32_t*)d_out, f, (uint32_t*)d_v, (uint32_t*)d_out, f, 1,
+                          (uint32_t)n_out));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_fold_scalars(int curve, const uint64_t* v, size_t n_out, const uint64_t s_lo[4], const uint64_t s_hi[4],
+                       uint64_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (n_out > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n_out == 0) return 0;
+  if (!v || !out || !s_lo || !s_hi) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(g_ctx.st_sc.ensure(2 * n_out * 32));
+  HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, v, 2 * n_out * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  FoldScalars f = make_fold_scalars(s_lo, s_hi);
+  uint32_t* d = g_ctx.st_sc.as<uint32_t>();
+  TRY(fold_scalars_launch(curve, d, d, f, d, d, f, 1, (uint32_t)n_out));
+  HIP_TRY(hipMemcpyAsync(out, d, n_out * 32, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_fold_points_device(int curve, const void* d_g, size_t n_out, const uint64_t s_lo[4],
+                             const uint64_t s_hi[4], void* d_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (n_out > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n_out && (!d_g || !d_out || !s_lo || !s_hi)) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(fold_points_launch(curve, (const uint32_t*)d_g, (uint32_t*)d_out, s_lo, s_hi, (const uint32_t*)d_g,
+                         (uint32_t*)d_out, s_lo, s_hi, 1, (uint32_t)n_out));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_fold_points(int curve, const uint64_t* g_xyz, size_t n_out, const uint64_t s_lo[4], const uint64_t s_hi[4],
+                      uint64_t* out_xyz) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (n_out > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n_out == 0) return 0;
+  if (!g_xyz || !out_xyz || !s_lo || !s_hi) return fail(BPGPU_E_ARG, "null pointer");
+  size_t n2 = 2 * n_out;
+  TRY(g_ctx.st_pts_in.ensure(n2 * 96));
+  TRY(g_ctx.st_pts.ensure(n2 * 64));
+  HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, g_xyz, n2 * 96, hipMemcpyHostToDevice, g_ctx.stream));
+  TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), g_ctx.st_pts.as<uint32_t>(), n2, 0));
+  uint32_t* d = g_ctx.st_pts.as<uint32_t>();
+  TRY(fold_points_launch(curve, d, d, s_lo, s_hi, d, d, s_lo, s_hi, 1, (uint32_t)n_out));
+  TRY(points_out(curve, d, g_ctx.st_pts_in.as<uint32_t>(), n_out));
+  HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_pts_in.p, n_out * 96, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+// ---- IPA prover session -----------------------------------------------------
+int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
+                    const uint64_t* a, const uint64_t* b, size_t n, bpgpu_ipa** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!out || !ip_gen_xyz) return fail(BPGPU_E_ARG, "null pointer");
+  if (n && (!a_gens_xyz || !b_gens_xyz || !a || !b)) return fail(BPGPU_E_ARG, "null pointer");
+  if (n > (1u << 30)) return fail(BPGPU_E_ARG, "n too large");
+  // zero_pad_to_two_power (util/mod.rs:137-144): next power of two, at least 1
+  size_t np = pow2_at_least(n < 1 ? 1 : n);
+  bpgpu_ipa* s = new bpgpu_ipa();
+  s->curve = curve;
+  s->np = np;
+  s->len = np;
+  s->lr_done = false;
+  s->d_pts = nullptr;
+  s->d_sc = nullptr;
+  auto cleanup = [&]() {
+    if (s->d_pts) (void)hipFree(s->d_pts);
+    if (s->d_sc) (void)hipFree(s->d_sc);
+    delete s;
+  };
+  hipError_t e = hipMalloc((void**)&s->d_pts, (2 * np + 1) * 64);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_sc, (2 * np + 2) * 32);
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(BPGPU_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  hipStream_t st = g_ctx.stream;
+  int rc = 0;
+  do {
+    // identity points / zero scalars are all-zero bytes in both device formats
+    if (hipMemsetAsync(s->d_pts, 0, (2 * np + 1) * 64, st) != hipSuccess ||
+        hipMemsetAsync(s->d_sc, 0, (2 * np + 2) * 32, st) != hipSuccess) {
+      rc = fail(BPGPU_E_HIP, "hipMemsetAsync failed");
+      break;
+    }
+    if ((rc = g_ctx.st_pts_in.ensure((2 * n + 1) * 96)) != 0) break;
+    uint8_t* stg = (uint8_t*)g_ctx.st_pts_in.p;
+    if (n) {
+      if (hipMemcpyAsync(stg, a_gens_xyz, n * 96, hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(stg + n * 96, b_gens_xyz, n * 96, hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(s->d_sc, a, n * 32, hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(s->d_sc + 8 * np, b, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) {
+        rc = fail(BPGPU_E_HIP, "upload failed");
+        break;
+      }
+    }
+    if (hipMemcpyAsync(stg + 2 * n * 96, ip_gen_xyz, 96, hipMemcpyHostToDevice, st) != hipSuccess) {
+      rc = fail(BPGPU_E_HIP, "upload failed");
+      break;
+    }
+    if ((rc = points_in(curve, (uint32_t*)stg, s->d_pts, n, 0)) != 0) break;
+    if ((rc = points_in(curve, (uint32_t*)(stg + n * 96), s->d_pts + 16 * np, n, 0)) != 0) break;
+    if ((rc = points_in(curve, (uint32_t*)(stg + 2 * n * 96), s->d_pts + 32 * np, 1, 0)) != 0) break;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = fail(BPGPU_E_HIP, "sync failed");
+  } while (0);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  *out = s;
+  return 0;
+}
+
+size_t bpgpu_ipa_len(const bpgpu_ipa* s) { return s ? s->len : 0; }
+
+int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (!s || !l_xy_inf || !r_xy_inf) return fail(BPGPU_E_ARG, "null pointer");
+  if (s->len <= 1) return fail(BPGPU_E_STATE, "the vectors already have length 1");
+  if (s->lr_done) return fail(BPGPU_E_STATE, "round_fold must follow round_lr");
+  const uint32_t n = (uint32_t)(s->len / 2), np = (uint32_t)s->np;
+  // c_L = <a[..n], b[n..]>, c_R = <a[n..], b[..n]>   (bp_iter.rs:73,80)
+  IpPair pl{0u, np + n}, pr{n, np};
+  TRY(ip_launch(s->curve, s->d_sc, pl, pr, 2, n, s->d_sc + 8ull * (2 * np), s->d_sc + 8ull * (2 * np + 1)));
+  MsmPlan plan;
+  memset(&plan, 0, sizeof plan);
+  plan.M = 2;
+  plan.n = 2 * n + 1;
+  // L = msm(A[n..] | B[..n] | Q,  a[..n] | b[n..] | c_L)   (bp_iter.rs:68-74)
+  plan.seg[0][0] = MsmSeg{n, 0u, n};
+  plan.seg[0][1] = MsmSeg{np, np + n, n};
+  plan.seg[0][2] = MsmSeg{2 * np, 2 * np, 1};
+  // R = msm(A[..n] | B[n..] | Q,  a[n..] | b[..n] | c_R)   (bp_iter.rs:75-81)
+  plan.seg[1][0] = MsmSeg{0u, n, n};
+  plan.seg[1][1] = MsmSeg{np + n, np, n};
+  plan.seg[1][2] = MsmSeg{2 * np, 2 * np + 1, 1};
+  uint64_t out[2][9];
+  TRY(msm_dispatch(s->curve, s->d_pts, s->d_sc, plan, out));
+  memcpy(l_xy_inf, out[0], 72);
+  memcpy(r_xy_inf, out[1], 72);
+  s->lr_done = true;
+  return 0;
+}
+
+int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (!s || !x || !x_inv) return fail(BPGPU_E_ARG, "null pointer");
+  if (!s->lr_done) return fail(BPGPU_E_STATE, "round_lr must precede round_fold");
+  const uint32_t n = (uint32_t)(s->len / 2), np = (uint32_t)s->np;
+  // a' = x a_lo + x^-1 a_hi;  b' = x^-1 b_lo + x b_hi          (bp_iter.rs:88-95)
+  FoldScalars fa = make_fold_scalars(x, x_inv), fb = make_fold_scalars(x_inv, x);
+  uint32_t* da = s->d_sc;
+  uint32_t* db = s->d_sc + 8ull * np;
+  TRY(fold_scalars_launch(s->curve, da, da, fa, db, db, fb, 2, n));
+  // A' = x^-1 A_lo + x A_hi;  B' = x B_lo + x^-1 B_hi          (bp_iter.rs:97-104)
+  uint32_t* dA = s->d_pts;
+  uint32_t* dB = s->d_pts + 16ull * np;
+  TRY(fold_points_launch(s->curve, dA, dA, x_inv, x, dB, dB, x, x_inv, 2, n));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  s->len = n;
+  s->lr_done = false;
+  return 0;
+}
+
+int bpgpu_ipa_finish(bpgpu_ipa* s, uint64_t final_a[4], uint64_t final_b[4]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (!s || !final_a || !final_b) return fail(BPGPU_E_ARG, "null pointer");
+  if (s->len != 1 || s->lr_done) return fail(BPGPU_E_STATE, "the loop has not finished");
+  HIP_TRY(hipMemcpyAsync(final_a, s->d_sc, 32, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(final_b, s->d_sc + 8ull * s->np, 32, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_ipa_export(bpgpu_ipa* s, uint64_t* a_gens_xyz, uint64_t* b_gens_xyz, uint64_t* a, uint64_t* b) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (!s) return fail(BPGPU_E_ARG, "null session");
+  if (s->lr_done) return fail(BPGPU_E_STATE, "export between round_lr and round_fold");
+  const size_t n = s->len, np = s->np;
+  hipStream_t st = g_ctx.stream;
+  TRY(g_ctx.st_out.ensure(n * 96));
+  if (a_gens_xyz) {
+    TRY(points_out(s->curve, s->d_pts, g_ctx.st_out.as<uint32_t>(), n));
+    HIP_TRY(hipMemcpyAsync(a_gens_xyz, g_ctx.st_out.p, n * 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  if (b_gens_xyz) {
+    TRY(points_out(s->curve, s->d_pts + 16ull * np, g_ctx.st_out.as<uint32_t>(), n));
+    HIP_TRY(hipMemcpyAsync(b_gens_xyz, g_ctx.st_out.p, n * 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  if (a) HIP_TRY(hipMemcpyAsync(a, s->d_sc, n * 32, hipMemcpyDeviceToHost, st));
+  if (b) HIP_TRY(hipMemcpyAsync(b, s->d_sc + 8ull * np, n * 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+void bpgpu_ipa_free(bpgpu_ipa* s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+  if (s->d_pts) (void)hipFree(s->d_pts);
+  if (s->d_sc) (void)hipFree(s->d_sc);
+  delete s;
+}
+
+// ---- sharded-MSM helper -----------------------------------------------------
+int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t out_xy_inf[9]) {
+  TRY(check_curve(curve));
+  if (!out_xy_inf || (count && !xy_inf)) return fail(BPGPU_E_ARG, "null pointer");
+  auto run = [&](auto tag) {
+    constexpr int BF = decltype(tag)::value;
+    using E = host::HEc<BF>;
+    host::HPoint<BF> acc = E::identity();
+    for (size_t i = 0; i < count; i++) {
+      const uint64_t* p = xy_inf + 9 * i;
+      if (p[8]) continue;
+      host::H4 x, y;
+      memcpy(x.v, p, 32);
+      memcpy(y.v, p + 4, 32);
+      acc = E::add(acc, E::from_affine(x, y));
+    }
+    write_xy_inf<BF>(acc, out_xy_inf);
+  };
+  if (curve == BPGPU_PALLAS)
+    run(std::integral_constant<int, 0>{});
+  else
+    run(std::integral_constant<int, 1>{});
+  return 0;
+}
+
+// ---- instrumentation ----------------------------------------------------------
+int bpgpu_last_msm_timings(float out_ms[8]) {
+  if (!out_ms) return fail(BPGPU_E_ARG, "null pointer");
+  memcpy(out_ms, g_ctx.msm_ms, sizeof g_ctx.msm_ms);
+  return 0;
+}
+
+int bpgpu_measure_mad_peak(double* mads_per_sec) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (!mads_per_sec) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(g_ctx.st_out.ensure(4096));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g_ctx.device));
+  const int iters = 8192, grid = prop.multiProcessorCount * 8;
+  hipStream_t st = g_ctx.stream;
+  k_mad_peak<<<grid, 256, 0, st>>>(g_ctx.st_out.as<uint32_t>(), 1u, iters);
+  HIP_TRY(hipStreamSynchronize(st));
+  float best = 1e30f;
+  for (int r = 0; r < 5; r++) {
+    HIP_TRY(hipEventRecord(g_ctx.ev[6], st));
+    k_mad_peak<<<grid, 256, 0, st>>>(g_ctx.st_out.as<uint32_t>(), (uint32_t)r + 2u, iters);
+    HIP_TRY(hipEventRecord(g_ctx.ev[7], st));
+    HIP_TRY(hipEventSynchronize(g_ctx.ev[7]));
+    float ms;
+    HIP_TRY(hipEventElapsedTime(&ms, g_ctx.ev[6], g_ctx.ev[7]));
+    if (ms < best) best = ms;
+  }
+  *mads_per_sec = (double)grid * 256.0 * iters * 32.0 / (best * 1e-3);
+  return 0;
+}
+
+}  // extern "C"

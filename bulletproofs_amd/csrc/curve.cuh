@@ -1,0 +1,262 @@
+// Pasta curve arithmetic (y^2 = x^3 + 5, a = 0) in extended Jacobian "XYZZ"
+// coordinates:  x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2.  One coordinate system serves the
+// bucket accumulation (mixed add 8M+2S), the bucket reduction / fix-ups (full add
+// 12M+2S) and the shared-scalar generator fold (doubling 6M+3S).
+//
+// Formulas: EFD madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1, restated for the
+// lazy signed-limb field of field.cuh (see the bound notes there); every special
+// case (identity operands, P + P, P + (-P)) is handled, behind a cheap low-limb
+// filter so the common path stays branch-free in practice.
+//
+// Reference semantics being reproduced: `buckets[..] += base`, `running_sum += &b`,
+// `total.double_in_place()` in src/util/msm.rs:148,169-170,187 and
+// `l.mul(&x_inv) + r.mul(&x)` in src/proofs/bp_iter.rs:99,103 -- as group operations;
+// the projective representative differs from ark-ec's Jacobian one, which is why
+// parity is defined on normalised (affine) elements.
+#pragma once
+#include "field.cuh"
+
+namespace bpgpu {
+
+// Affine point in device form; inf encodes the identity.
+struct Aff {
+  Fe x, y;
+  bool inf;
+};
+
+struct Xyzz {
+  Fe x, y, zz, zzz;
+  bool inf;
+};
+
+template <int FID>
+struct Ec {
+  using F = Fp<FID>;
+
+  static BP_HD Xyzz identity() {
+    Xyzz r;
+    r.x = F::zero();
+    r.y = F::zero();
+    r.zz = F::zero();
+    r.zzz = F::zero();
+    r.inf = true;
+    return r;
+  }
+  static BP_HD Xyzz from_affine(const Aff& p) {
+    if (p.inf) return identity();
+    Xyzz r;
+    r.x = p.x;
+    r.y = F::carry(p.y);  // p.y may be a negated (non-positive-limb) value
+    r.zz = F::one();
+    r.zzz = F::one();
+    r.inf = false;
+    return r;
+  }
+  // -p: limbs of y become non-positive (|limb| < 2^29), fine as a mul operand
+  static BP_HD Aff neg(const Aff& p) {
+    Aff r = p;
+    r.y = F::neg(p.y);
+    return r;
+  }
+  static BP_HD Xyzz neg(const Xyzz& p) {
+    Xyzz r = p;
+    r.y = F::carry(F::neg(p.y));
+    return r;
+  }
+  // XYZZ -> affine (one field inversion)
+  static BP_HD Aff to_affine(const Xyzz& p) {
+    Aff r;
+    r.inf = p.inf;
+    if (p.inf) {
+      r.x = F::zero();
+      r.y = F::zero();
+      return r;
+    }
+    Fe i = F::inv(F::mul(p.zz, p.zzz));
+    r.x = F::mul(p.x, F::mul(i, p.zzz));
+    r.y = F::mul(p.y, F::mul(i, p.zz));
+    return r;
+  }
+
+  // 2*(x, y) for an affine non-identity point (mdbl-2008-s-1); y != 0 always holds on
+  // a prime-order curve.
+  static BP_HD Xyzz dbl_affine(const Aff& p) {
+    if (p.inf) return identity();
+    Xyzz r;
+    Fe U = F::carry(F::add(p.y, p.y));
+    Fe V = F::sqr(U);
+    Fe W = F::mul(U, V);
+    Fe S = F::mul(p.x, V);
+    Fe M = F::carry(F::mul_small(F::sqr(p.x), 3));
+    Fe X3 = F::carry(F::sub(F::sub(F::sqr(M), S), S));
+    Fe Y3 = F::carry(F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y)));
+    r.x = X3;
+    r.y = Y3;
+    r.zz = V;
+    r.zzz = W;
+    r.inf = false;
+    return r;
+  }
+
+  // dbl-2008-s-1
+  static BP_HD Xyzz dbl(const Xyzz& p) {
+    if (p.inf) return p;
+    Xyzz r;
+    Fe U = F::carry(F::add(p.y, p.y));
+    Fe V = F::sqr(U);
+    Fe W = F::mul(U, V);
+    Fe S = F::mul(p.x, V);
+    Fe M = F::carry(F::mul_small(F::sqr(p.x), 3));
+    Fe X3 = F::carry(F::sub(F::sub(F::sqr(M), S), S));
+    Fe Y3 = F::carry(F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y)));
+    r.x = X3;
+    r.y = Y3;
+    r.zz = F::mul(V, p.zz);
+    r.zzz = F::mul(W, p.zzz);
+    r.inf = false;
+    return r;
+  }
+
+  // acc += q  (q affine; madd-2008-s).  acc.x / acc.y are kept carried.
+  static BP_HD void madd(Xyzz& acc, const Aff& q) {
+    if (q.inf) return;
+    if (acc.inf) {
+      acc = from_affine(q);
+      return;
+    }
+    Fe U2 = F::mul(q.x, acc.zz);
+    Fe S2 = F::mul(q.y, acc.zzz);
+    Fe P = F::sub(U2, acc.x);
+    Fe R = F::sub(S2, acc.y);
+    if (F::is_zero(P)) {
+      if (F::is_zero(R)) {
+        acc = dbl_affine(q);
+      } else {
+        acc = identity();
+      }
+      return;
+    }
+    Fe PP = F::sqr(P);
+    Fe PPP = F::mul(P, PP);
+    Fe Q = F::mul(acc.x, PP);
+    Fe X3 = F::carry(F::sub(F::sub(F::sub(F::sqr(R), PPP), Q), Q));
+    Fe Y3 = F::carry(F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP)));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = F::mul(acc.zz, PP);
+    acc.zzz = F::mul(acc.zzz, PPP);
+  }
+
+  // a + b, both XYZZ (add-2008-s)
+  static BP_HD Xyzz add(const Xyzz& a, const Xyzz& b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    Fe U1 = F::mul(a.x, b.zz);
+    Fe U2 = F::mul(b.x, a.zz);
+    Fe S1 = F::mul(a.y, b.zzz);
+    Fe S2 = F::mul(b.y, a.zzz);
+    Fe P = F::sub(U2, U1);
+    Fe R = F::sub(S2, S1);
+    if (F::is_zero(P)) {
+      if (F::is_zero(R)) return dbl(a);
+      return identity();
+    }
+    Xyzz r;
+    Fe PP = F::sqr(P);
+    Fe PPP = F::mul(P, PP);
+    Fe Q = F::mul(U1, PP);
+    Fe X3 = F::carry(F::sub(F::sub(F::sub(F::sqr(R), PPP), Q), Q));
+    Fe Y3 = F::carry(F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP)));
+    r.x = X3;
+    r.y = Y3;
+    r.zz = F::mul(F::mul(a.zz, b.zz), PP);
+    r.zzz = F::mul(F::mul(a.zzz, b.zzz), PPP);
+    r.inf = false;
+    return r;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Memory formats (all little-endian u32 words)
+//   ark affine   : x[8] y[8]           canonical, value*2^256  (0,0) = identity
+//   ark jacobian : X[8] Y[8] Z[8]      canonical, value*2^256  Z = 0  = identity
+//   dev affine   : x[8] y[8]           canonical, value*2^261  (0,0) = identity
+//   dev xyzz     : X[8] Y[8] ZZ[8] ZZZ[8]  canonical, value*2^261, ZZ = 0 = identity
+// ---------------------------------------------------------------------------
+template <int FID>
+struct PointIo {
+  using F = Fp<FID>;
+
+  static BP_HD bool all_zero(const uint32_t (&w)[8]) {
+    uint32_t a = 0;
+    BP_UNROLL
+    for (int i = 0; i < 8; i++) a |= w[i];
+    return a == 0;
+  }
+
+  static BP_HD Aff load_dev_affine(const uint32_t* p) {
+    uint32_t wx[8], wy[8];
+    BP_UNROLL
+    for (int i = 0; i < 8; i++) {
+      wx[i] = p[i];
+      wy[i] = p[8 + i];
+    }
+    Aff r;
+    r.inf = all_zero(wx) && all_zero(wy);
+    r.x = F::unpack(wx);
+    r.y = F::unpack(wy);
+    return r;
+  }
+  static BP_HD void store_dev_affine(uint32_t* p, const Aff& a) {
+    uint32_t wx[8], wy[8];
+    F::store_packed(a.x, wx);
+    F::store_packed(a.y, wy);
+    BP_UNROLL
+    for (int i = 0; i < 8; i++) {
+      p[i] = a.inf ? 0u : wx[i];
+      p[8 + i] = a.inf ? 0u : wy[i];
+    }
+  }
+  static BP_HD Xyzz load_dev_xyzz(const uint32_t* p) {
+    uint32_t w[4][8];
+    BP_UNROLL
+    for (int c = 0; c < 4; c++) {
+      BP_UNROLL
+      for (int i = 0; i < 8; i++) w[c][i] = p[8 * c + i];
+    }
+    Xyzz r;
+    r.inf = all_zero(w[2]);
+    r.x = F::unpack(w[0]);
+    r.y = F::unpack(w[1]);
+    r.zz = F::unpack(w[2]);
+    r.zzz = F::unpack(w[3]);
+    return r;
+  }
+  static BP_HD void store_dev_xyzz(uint32_t* p, const Xyzz& a) {
+    uint32_t w[4][8];
+    F::store_packed(a.x, w[0]);
+    F::store_packed(a.y, w[1]);
+    F::store_packed(a.zz, w[2]);
+    F::store_packed(a.zzz, w[3]);
+    BP_UNROLL
+    for (int c = 0; c < 4; c++) {
+      BP_UNROLL
+      for (int i = 0; i < 8; i++) p[8 * c + i] = a.inf ? 0u : w[c][i];
+    }
+  }
+  // XYZZ in ark form (value*2^256) for the host tail
+  static BP_HD void store_ark_xyzz(uint32_t* p, const Xyzz& a) {
+    uint32_t w[4][8];
+    F::store_ark(a.x, w[0]);
+    F::store_ark(a.y, w[1]);
+    F::store_ark(a.zz, w[2]);
+    F::store_ark(a.zzz, w[3]);
+    BP_UNROLL
+    for (int c = 0; c < 4; c++) {
+      BP_UNROLL
+      for (int i = 0; i < 8; i++) p[8 * c + i] = a.inf ? 0u : w[c][i];
+    }
+  }
+};
+
+}  // namespace bpgpu

@@ -1,0 +1,487 @@
+// Device kernels of the MSM + IPA-folding hot path (gfx950).  Host entry points are in
+// bpgpu.hip; arithmetic is in field.cuh / curve.cuh.
+//
+// MSM pipeline (reference algorithm being replaced: pippenger_msm, src/util/msm.rs:88-193):
+//   k_digits<HIST>   scalar -> canonical -> signed c-bit digits; per-bucket histogram
+//   k_scan           exclusive prefix sum over all M*W*B bucket counts
+//   k_digits<SCAT>   same digits again; scatter point indices into bucket-sorted order
+//   k_accum          one lane per bucket: mixed additions of its points (XYZZ accumulator)
+//   k_reduce1        one lane per run of S buckets: running-sum reduction (msm.rs:167-171)
+//   k_reduce2        one workgroup per window: tree-sum of the run results
+// The Horner combine over the W window sums (msm.rs:177-190) is a few hundred dependent
+// group operations and runs on the host (host_field.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "curve.cuh"
+
+namespace bpgpu {
+
+// One MSM operand is the concatenation of up to 3 ranges of a device point array and a
+// device scalar array (the prover's L/R operands, bp_iter.rs:68-81, are such
+// concatenations of halves of A, B, a, b plus the single pair (Q, <a,b>)).
+struct MsmSeg {
+  uint32_t pt_off, sc_off, count;
+};
+struct MsmPlan {
+  int M;       // number of independent MSMs in this batch (1 or 2)
+  int W;       // windows per MSM
+  int c;       // window width in bits; digits are signed, |d| <= 2^(c-1)
+  uint32_t n;  // slots per MSM (sum of its segment counts)
+  MsmSeg seg[2][3];
+};
+
+__device__ __forceinline__ uint32_t extract_bits(const uint32_t (&w)[8], int pos, int c) {
+  // bits [pos, pos+c) of the 256-bit little-endian value, c <= 24
+  int wi = pos >> 5, sh = pos & 31;
+  if (wi >= 8) return 0;
+  uint64_t v = w[wi];
+  if (wi + 1 < 8) v |= (uint64_t)w[wi + 1] << 32;
+  return (uint32_t)(v >> sh) & ((1u << c) - 1u);
+}
+
+// SF = scalar field id.  MODE 0: histogram; MODE 1: scatter.
+template <int SF, int MODE>
+__global__ void __launch_bounds__(256) k_digits(MsmPlan plan, const uint32_t* __restrict__ scalars,
+                                                uint32_t* __restrict__ counts,  // hist (MODE 0) / cursor (MODE 1)
+                                                uint32_t* __restrict__ sorted) {
+  using F = Fp<SF>;
+  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (uint64_t)plan.M * plan.n) return;
+  int m = (int)(gid / plan.n);
+  uint32_t t = (uint32_t)(gid % plan.n);
+  int s = 0;
+  while (s < 2 && t >= plan.seg[m][s].count) {
+    t -= plan.seg[m][s].count;
+    s++;
+  }
+  uint32_t pt_idx = plan.seg[m][s].pt_off + t;
+  const uint32_t* sp = scalars + 8ull * (plan.seg[m][s].sc_off + t);
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = sp[i];
+  // ark form s*2^256  ->  canonical s   (into_repr at msm.rs:96)
+  Fe v = F::mul(F::unpack(w), F::from_const(F::C::C256TOCANON));
+  F::pack(F::canon(v), w);
+  const int c = plan.c;
+  const uint32_t half = 1u << (c - 1);
+  uint32_t carry = 0;
+  for (int j = 0; j < plan.W; j++) {
+    uint32_t bits = extract_bits(w, j * c, c) + carry;
+    uint32_t neg = bits > half ? 1u : 0u;
+    uint32_t mag = neg ? (1u << c) - bits : bits;
+    carry = neg;
+    if (mag != 0) {
+      uint32_t key = ((uint32_t)(m * plan.W + j) << (c - 1)) + (mag - 1);
+      if (MODE == 0) {
+        atomicAdd(&counts[key], 1u);
+      } else {
+        uint32_t pos = atomicAdd(&counts[key], 1u);
+        sorted[pos] = pt_idx | (neg << 31);
+      }
+    }
+  }
+}
+
+// Exclusive prefix sum of counts[0..n) into offs[0..n] (offs[n] = total) and a copy
+// into cursor[0..n).  One workgroup; n is at most a few million.
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs,
+                                               uint32_t* __restrict__ cursor, uint32_t n) {
+  __shared__ uint32_t part[1024];
+  uint32_t tid = threadIdx.x;
+  uint32_t per = (n + 1023) / 1024;
+  uint32_t lo = tid * per, hi = min(lo + per, n);
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += counts[i];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - s;
+  for (uint32_t i = lo; i < hi; i++) {
+    offs[i] = run;
+    cursor[i] = run;
+    run += counts[i];
+  }
+  if (tid == 1023) offs[n] = part[1023];
+}
+
+// One lane per bucket.  BF = base field id.
+template <int BF>
+__global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
+                                               const uint32_t* __restrict__ sorted, uint32_t* __restrict__ bsum,
+                                               uint32_t nbuckets) {
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  uint32_t lo = offs[b], hi = offs[b + 1];
+  Xyzz acc = E::identity();
+  for (uint32_t e = lo; e < hi; e++) {
+    uint32_t ent = sorted[e];
+    Aff q = IO::load_dev_affine(points + 16ull * (ent & 0x7fffffffu));
+    if (ent >> 31) q = E::neg(q);
+    E::madd(acc, q);
+  }
+  IO::store_dev_xyzz(bsum + 32ull * b, acc);
+}
+
+// One lane per run of S = 2^s consecutive buckets of one window.  With k0 the
+// window-local index of the run's first bucket (bucket k has weight k+1):
+//   sum_k (k+1) B_k = sum_k (k-k0+1) B_k + k0 * sum_k B_k
+template <int BF>
+__global__ void __launch_bounds__(256) k_reduce1(const uint32_t* __restrict__ bsum, uint32_t* __restrict__ partial,
+                                                 uint32_t nruns, int s, int cm1) {
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nruns) return;
+  uint32_t S = 1u << s;
+  uint32_t first = r << s;
+  uint32_t k0 = first & ((1u << cm1) - 1u);
+  Xyzz running = E::identity(), total = E::identity();
+  for (int k = (int)S - 1; k >= 0; k--) {
+    Xyzz bk = IO::load_dev_xyzz(bsum + 32ull * (first + k));
+    running = E::add(running, bk);
+    total = E::add(total, running);
+  }
+  if (k0 != 0) {
+    Xyzz t = E::identity();
+    for (int bit = cm1 - 1; bit >= 0; bit--) {
+      t = E::dbl(t);
+      if ((k0 >> bit) & 1u) t = E::add(t, running);
+    }
+    total = E::add(total, t);
+  }
+  IO::store_dev_xyzz(partial + 32ull * r, total);
+}
+
+// One workgroup per window: out[w] = sum of partial[w*per .. (w+1)*per), ark-form XYZZ.
+template <int BF>
+__global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* __restrict__ out,
+                                                 uint32_t per) {
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  __shared__ uint32_t sh[256 * 33];  // padded rows: 33 dwords per lane
+  uint32_t w = blockIdx.x, tid = threadIdx.x;
+  Xyzz acc = E::identity();
+  for (uint32_t i = tid; i < per; i += 256) {
+    Xyzz p = IO::load_dev_xyzz(partial + 32ull * ((uint64_t)w * per + i));
+    acc = E::add(acc, p);
+  }
+  for (uint32_t d = 128; d >= 1; d >>= 1) {
+    __syncthreads();
+    if (tid >= d && tid < 2 * d) IO::store_dev_xyzz(sh + 33 * tid, acc);
+    __syncthreads();
+    if (tid < d) {
+      Xyzz p = IO::load_dev_xyzz(sh + 33 * (tid + d));
+      acc = E::add(acc, p);
+    }
+  }
+  if (tid == 0) IO::store_ark_xyzz(out + 32ull * w, acc);
+}
+
+// ---------------------------------------------------------------------------
+// Format conversion kernels
+// ---------------------------------------------------------------------------
+// ark jacobian (96 B) or ark affine (64 B) -> dev affine (64 B)
+template <int BF>
+__global__ void __launch_bounds__(256) k_points_in(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                   uint32_t n, int fmt) {
+  using F = Fp<BF>;
+  using IO = PointIo<BF>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t wx[8], wy[8], wz[8];
+  const uint32_t* p = in + (uint64_t)i * (fmt == 0 ? 24 : 16);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    wx[k] = p[k];
+    wy[k] = p[8 + k];
+  }
+  Aff a;
+  if (fmt == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) wz[k] = p[16 + k];
+    bool z_one = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      z_one = z_one && wz[2 * k] == (uint32_t)F::C::H_ONE[k] && wz[2 * k + 1] == (uint32_t)(F::C::H_ONE[k] >> 32);
+    }
+    a.inf = IO::all_zero(wz);
+    a.x = F::load_ark(wx);
+    a.y = F::load_ark(wy);
+    if (!z_one && !a.inf) {
+      Fe z = F::load_ark(wz);
+      Fe zi = F::inv(z);
+      Fe zi2 = F::sqr(zi);
+      a.x = F::mul(a.x, zi2);
+      a.y = F::mul(a.y, F::mul(zi2, zi));
+    }
+  } else {
+    a.inf = IO::all_zero(wx) && IO::all_zero(wy);
+    a.x = F::load_ark(wx);
+    a.y = F::load_ark(wy);
+  }
+  IO::store_dev_affine(out + 16ull * i, a);
+}
+
+// dev affine -> ark jacobian with Z = 1, identity = (0, 1, 0)  (ark-ec's zero())
+template <int BF>
+__global__ void __launch_bounds__(256) k_points_out(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                    uint32_t n) {
+  using F = Fp<BF>;
+  using IO = PointIo<BF>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff a = IO::load_dev_affine(in + 16ull * i);
+  uint32_t wx[8], wy[8];
+  F::store_ark(a.x, wx);
+  F::store_ark(a.y, wy);
+  uint32_t* o = out + 24ull * i;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t one_lo = (uint32_t)F::C::H_ONE[k], one_hi = (uint32_t)(F::C::H_ONE[k] >> 32);
+    o[2 * k] = a.inf ? 0u : wx[2 * k];
+    o[2 * k + 1] = a.inf ? 0u : wx[2 * k + 1];
+    o[8 + 2 * k] = a.inf ? one_lo : wy[2 * k];
+    o[8 + 2 * k + 1] = a.inf ? one_hi : wy[2 * k + 1];
+    o[16 + 2 * k] = a.inf ? 0u : one_lo;
+    o[16 + 2 * k + 1] = a.inf ? 0u : one_hi;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Scalar-vector kernels (scalar field SF); vectors are in ark form (value*2^256)
+// ---------------------------------------------------------------------------
+// a (|value| < 100p, any lazy limbs)  ->  carried limbs, value in (-2^130, 2^254 + 2^130):
+// subtracts floor(value / 2^254) * p so that long sums can go on without growing
+template <int SF>
+__device__ __forceinline__ Fe fe_partial_reduce(const Fe& a) {
+  using F = Fp<SF>;
+  Fe r = F::carry(a);
+  int32_t k = r.l[8] >> 22;  // floor(value / 2^254), |k| <= 128
+  int64_t cy = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    int64_t s = (int64_t)r.l[i] - (int64_t)k * (int64_t)F::C::P29[i] + cy;
+    r.l[i] = (int32_t)((uint32_t)s & MASK29);
+    cy = s >> 29;
+  }
+#pragma unroll
+  for (int i = 5; i < 8; i++) {
+    int32_t s = r.l[i] + (int32_t)cy;
+    r.l[i] = s & (int32_t)MASK29;
+    cy = s >> 29;
+  }
+  r.l[8] = r.l[8] - k * (int32_t)F::C::P29[8] + (int32_t)cy;
+  return r;
+}
+
+struct IpPair {
+  uint32_t a_off, b_off;  // element offsets into the scalar array
+};
+
+// partial[blockIdx.y][blockIdx.x] = sum over this block's slice of a[i]*b[i] (device form of the
+// *ark-form product*, see k_ip_final).  Up to two inner products per launch (the round's
+// <a_lo,b_hi> and <a_hi,b_lo>, bp_iter.rs:73,80).
+template <int SF>
+__global__ void __launch_bounds__(256) k_ip_partial(const uint32_t* __restrict__ sc, IpPair p0, IpPair p1, uint32_t n,
+                                                    uint32_t* __restrict__ partial) {
+  using F = Fp<SF>;
+  __shared__ int32_t sh[256 * 9];
+  IpPair pr = blockIdx.y == 0 ? p0 : p1;
+  const uint32_t* a = sc + 8ull * pr.a_off;
+  const uint32_t* b = sc + 8ull * pr.b_off;
+  uint32_t tid = threadIdx.x;
+  Fe acc = F::zero();
+  for (uint32_t i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+    uint32_t wa[8], wb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      wa[k] = a[8ull * i + k];
+      wb[k] = b[8ull * i + k];
+    }
+    // (a 2^256)(b 2^256)/2^261 = ab 2^251
+    Fe pdt = F::mul(F::unpack(wa), F::unpack(wb));
+    acc = fe_partial_reduce<SF>(F::add(acc, pdt));
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) sh[k * 256 + tid] = acc.l[k];
+  for (uint32_t d = 128; d >= 1; d >>= 1) {
+    __syncthreads();
+    if (tid < d) {
+      Fe o;
+#pragma unroll
+      for (int k = 0; k < 9; k++) o.l[k] = sh[k * 256 + tid + d];
+      acc = fe_partial_reduce<SF>(F::add(acc, o));
+#pragma unroll
+      for (int k = 0; k < 9; k++) sh[k * 256 + tid] = acc.l[k];
+    }
+  }
+  if (tid == 0) {
+    uint32_t w[8];
+    F::store_packed(acc, w);
+    uint32_t* o = partial + 8ull * (blockIdx.y * gridDim.x + blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = w[k];
+  }
+}
+
+// out[y] = (sum_x partial[y][x]) * 2^5   i.e. ab 2^251 -> ab 2^256 (ark form)
+template <int SF>
+__global__ void __launch_bounds__(64) k_ip_final(const uint32_t* __restrict__ partial, uint32_t nparts,
+                                                 uint32_t* __restrict__ out0, uint32_t* __restrict__ out1) {
+  using F = Fp<SF>;
+  if (threadIdx.x != 0) return;
+  Fe acc = F::zero();
+  for (uint32_t i = 0; i < nparts; i++) {
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = partial[8ull * (blockIdx.x * nparts + i) + k];
+    acc = fe_partial_reduce<SF>(F::add(acc, F::unpack(w)));
+  }
+  // montmul(x 2^251, 2^266) = x 2^256
+  Fe r = F::mul(acc, F::from_const(F::C::C256TO261));
+  uint32_t w[8];
+  F::store_packed(r, w);
+  uint32_t* o = blockIdx.x == 0 ? out0 : out1;
+#pragma unroll
+  for (int k = 0; k < 8; k++) o[k] = w[k];
+}
+
+struct FoldScalars {
+  uint32_t lo[8], hi[8];  // ark form
+};
+
+// out[i] = s_lo v[i] + s_hi v[i+n]  (bp_iter.rs:88-95).  blockIdx.y selects one of two
+// vectors (a with (x, x^-1) and b with (x^-1, x) in the same launch).
+template <int SF>
+__global__ void __launch_bounds__(256) k_fold_scalars(uint32_t* __restrict__ v0, uint32_t* __restrict__ o0,
+                                                      FoldScalars s0, uint32_t* __restrict__ v1,
+                                                      uint32_t* __restrict__ o1, FoldScalars s1, uint32_t n) {
+  using F = Fp<SF>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* v = blockIdx.y == 0 ? v0 : v1;
+  uint32_t* o = blockIdx.y == 0 ? o0 : o1;
+  const FoldScalars& s = blockIdx.y == 0 ? s0 : s1;
+  // device form of the two multipliers: montmul(v 2^256, s 2^261) = vs 2^256, ark form again
+  Fe slo = F::load_ark(s.lo), shi = F::load_ark(s.hi);
+  uint32_t wl[8], wh[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    wl[k] = v[8ull * i + k];
+    wh[k] = v[8ull * (i + n) + k];
+  }
+  Fe r = F::add(F::mul(F::unpack(wl), slo), F::mul(F::unpack(wh), shi));
+  uint32_t w[8];
+  F::store_packed(r, w);
+#pragma unroll
+  for (int k = 0; k < 8; k++) o[8ull * i + k] = w[k];
+}
+
+// ---------------------------------------------------------------------------
+// Generator fold (base field BF):  out[i] = s_lo * g[i] + s_hi * g[i+n]
+// (bp_iter.rs:97-104).  Every lane uses the same two scalars, so the joint sparse form
+// of (s_lo, s_hi) is recoded once on the host and the whole grid follows one
+// branch-uniform double-and-add schedule: 4-bit codes, most significant first,
+//   code & 7: 0 none, 1 P, 2 Q, 3 P+Q, 4 P-Q;  code & 8: negate.
+// ---------------------------------------------------------------------------
+struct FoldPlan {
+  uint32_t codes[33];  // up to 257 positions, 8 per word, position 0 = least significant
+  int len;
+  uint32_t s_lo[8], s_hi[8];  // canonical scalars (slow path only)
+};
+
+template <int BF>
+__device__ Xyzz mul_bits(const Aff& p, const uint32_t (&k)[8]) {
+  using E = Ec<BF>;
+  Xyzz acc = E::identity();
+  for (int i = 255; i >= 0; i--) {
+    acc = E::dbl(acc);
+    if ((k[i >> 5] >> (i & 31)) & 1u) E::madd(acc, p);
+  }
+  return acc;
+}
+
+template <int BF>
+__global__ void __launch_bounds__(256) k_fold_points(const uint32_t* __restrict__ g0, uint32_t* __restrict__ o0,
+                                                     FoldPlan f0, const uint32_t* __restrict__ g1,
+                                                     uint32_t* __restrict__ o1, FoldPlan f1, uint32_t n) {
+  using F = Fp<BF>;
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
+  uint32_t* o = blockIdx.y == 0 ? o0 : o1;
+  const FoldPlan& f = blockIdx.y == 0 ? f0 : f1;
+  Aff P = IO::load_dev_affine(g + 16ull * i);
+  Aff Q = IO::load_dev_affine(g + 16ull * (i + n));
+  Fe dx = F::sub(Q.x, P.x);
+  Xyzz acc;
+  if (P.inf || Q.inf || F::is_zero(dx)) {
+    // padding (identity) or P = +-Q: two independent ladders
+    Xyzz r1 = mul_bits<BF>(P, f.s_lo);
+    Xyzz r2 = mul_bits<BF>(Q, f.s_hi);
+    acc = E::add(r1, r2);
+  } else {
+    // P+Q and P-Q in affine, sharing the inversion of (xQ - xP)
+    Fe inv = F::inv(dx);
+    Aff S, D;
+    {
+      Fe lam = F::mul(F::sub(Q.y, P.y), inv);
+      Fe x3 = F::carry(F::sub(F::sub(F::sqr(lam), P.x), Q.x));
+      S.x = x3;
+      S.y = F::carry(F::sub(F::mul(lam, F::sub(P.x, x3)), P.y));
+      S.inf = false;
+      Fe lam2 = F::mul(F::neg(F::add(Q.y, P.y)), inv);
+      Fe x4 = F::carry(F::sub(F::sub(F::sqr(lam2), P.x), Q.x));
+      D.x = x4;
+      D.y = F::carry(F::sub(F::mul(lam2, F::sub(P.x, x4)), P.y));
+      D.inf = false;
+    }
+    acc = E::identity();
+    for (int pos = f.len - 1; pos >= 0; pos--) {
+      acc = E::dbl(acc);
+      uint32_t code = (f.codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;
+      uint32_t sel = code & 7u;
+      if (sel) {
+        Aff t = sel == 1 ? P : (sel == 2 ? Q : (sel == 3 ? S : D));
+        if (code & 8u) t = E::neg(t);
+        E::madd(acc, t);
+      }
+    }
+  }
+  Aff r = E::to_affine(acc);
+  IO::store_dev_affine(o + 16ull * i, r);
+}
+
+// Register-only multiply-add loop: sustained v_mad_u64_u32 issue rate (the integer
+// roofline the MSM and the generator fold are priced against).
+__global__ void __launch_bounds__(256) k_mad_peak(uint32_t* out, uint32_t seed, int iters) {
+  uint32_t a = seed + threadIdx.x, b = seed * 3u + blockIdx.x;
+  uint64_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = a + i;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
+      }
+    }
+  }
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s += acc[i];
+  if (s == 0x1234567) out[0] = (uint32_t)s;
+}
+
+}  // namespace bpgpu

@@ -1,0 +1,285 @@
+"""ctypes binding of the C ABI in include/bpgpu.h (libbpgpu.so, built in-tree by `make`).
+
+Plumbing only: numpy uint64 arrays in ark-ff memory layout go in, numpy arrays come out.
+There is no CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_double, c_float, c_int, c_size_t, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbpgpu.so")
+
+PALLAS, VESTA = 0, 1
+
+# every symbol include/bpgpu.h declares: name -> (restype, argtypes)
+_U64P = POINTER(c_uint64)
+SIGNATURES = {
+    "bpgpu_init": (c_int, [c_int]),
+    "bpgpu_shutdown": (None, []),
+    "bpgpu_last_error": (ctypes.c_char_p, []),
+    "bpgpu_set_window_bits": (c_int, [c_int]),
+    "bpgpu_msm": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_msm_affine": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_ip": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_fold_scalars": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "bpgpu_fold_points": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "bpgpu_dev_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
+    "bpgpu_dev_free": (c_int, [c_void_p]),
+    "bpgpu_dev_upload": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "bpgpu_dev_download": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "bpgpu_points_to_device": (c_int, [c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "bpgpu_points_from_device": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_msm_device": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_ip_device": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_fold_scalars_device": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "bpgpu_fold_points_device": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "bpgpu_ipa_begin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "bpgpu_ipa_len": (c_size_t, [c_void_p]),
+    "bpgpu_ipa_round_lr": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "bpgpu_ipa_round_fold": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "bpgpu_ipa_finish": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "bpgpu_ipa_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bpgpu_ipa_free": (None, [c_void_p]),
+    "bpgpu_points_sum": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_last_msm_timings": (c_int, [POINTER(c_float)]),
+    "bpgpu_measure_mad_peak": (c_int, [POINTER(c_double)]),
+}
+
+
+class BpGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libbpgpu.so and declare its prototypes.  Needs no GPU (bpgpu_init does)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BpGpuError(f"{LIB_PATH} is missing: build it with `make` (hipcc, gfx950); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise BpGpuError(f"bpgpu error {rc}: {load().bpgpu_last_error().decode()}")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _u64(a, words=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if words is not None:
+        a = a.reshape(-1, words)
+    return a
+
+
+def init(device: int = 0):
+    _check(load().bpgpu_init(device))
+
+
+def shutdown():
+    load().bpgpu_shutdown()
+
+
+def set_window_bits(c: int):
+    _check(load().bpgpu_set_window_bits(c))
+
+
+def msm(curve, points_xyz, scalars):
+    """points_xyz: (n, 12) u64 ark jacobian; scalars: (n, 4) u64 ark form -> (9,) u64 xy_inf"""
+    p, s = _u64(points_xyz, 12), _u64(scalars, 4)
+    n = min(len(p), len(s))  # the reference zips (msm.rs:94-97)
+    out = np.zeros(9, dtype=np.uint64)
+    _check(load().bpgpu_msm(curve, _ptr(p), _ptr(s), n, _ptr(out)))
+    return out
+
+
+def msm_affine(curve, points_xy, scalars):
+    p, s = _u64(points_xy, 8), _u64(scalars, 4)
+    n = min(len(p), len(s))
+    out = np.zeros(9, dtype=np.uint64)
+    _check(load().bpgpu_msm_affine(curve, _ptr(p), _ptr(s), n, _ptr(out)))
+    return out
+
+
+def ip(curve, a, b):
+    a, b = _u64(a, 4), _u64(b, 4)
+    if len(a) != len(b):
+        raise AssertionError("ip: length mismatch")  # reference asserts (util/mod.rs:18)
+    out = np.zeros(4, dtype=np.uint64)
+    _check(load().bpgpu_ip(curve, _ptr(a), _ptr(b), len(a), _ptr(out)))
+    return out
+
+
+def fold_scalars(curve, v, s_lo, s_hi):
+    v = _u64(v, 4)
+    assert len(v) % 2 == 0
+    n = len(v) // 2
+    out = np.zeros((n, 4), dtype=np.uint64)
+    _check(load().bpgpu_fold_scalars(curve, _ptr(v), n, _ptr(_u64(s_lo)), _ptr(_u64(s_hi)), _ptr(out)))
+    return out
+
+
+def fold_points(curve, g_xyz, s_lo, s_hi):
+    g = _u64(g_xyz, 12)
+    assert len(g) % 2 == 0
+    n = len(g) // 2
+    out = np.zeros((n, 12), dtype=np.uint64)
+    _check(load().bpgpu_fold_points(curve, _ptr(g), n, _ptr(_u64(s_lo)), _ptr(_u64(s_hi)), _ptr(out)))
+    return out
+
+
+def points_sum(curve, xy_inf):
+    x = _u64(xy_inf, 9)
+    out = np.zeros(9, dtype=np.uint64)
+    _check(load().bpgpu_points_sum(curve, _ptr(x), len(x), _ptr(out)))
+    return out
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes owned through the C ABI."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = nbytes
+        p = c_void_p()
+        _check(load().bpgpu_dev_alloc(nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check(load().bpgpu_dev_upload(self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype=np.uint64, count=None):
+        out = np.zeros(self.nbytes // np.dtype(dtype).itemsize if count is None else count, dtype=dtype)
+        _check(load().bpgpu_dev_download(_ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _check(load().bpgpu_dev_free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def points_to_device(curve, points, fmt=0):
+    p = _u64(points, 12 if fmt == 0 else 8)
+    buf = DeviceBuffer(max(1, len(p)) * 64)
+    _check(load().bpgpu_points_to_device(curve, _ptr(p), len(p), fmt, buf.ptr))
+    return buf
+
+
+def points_from_device(curve, buf, n):
+    out = np.zeros((n, 12), dtype=np.uint64)
+    _check(load().bpgpu_points_from_device(curve, buf.ptr, n, _ptr(out)))
+    return out
+
+
+def scalars_to_device(scalars):
+    s = _u64(scalars, 4)
+    return DeviceBuffer(max(1, len(s)) * 32).upload(s)
+
+
+def msm_device(curve, d_points, d_scalars, n):
+    out = np.zeros(9, dtype=np.uint64)
+    _check(load().bpgpu_msm_device(curve, d_points.ptr, d_scalars.ptr, n, _ptr(out)))
+    return out
+
+
+def ip_device(curve, d_a, d_b, n):
+    out = np.zeros(4, dtype=np.uint64)
+    _check(load().bpgpu_ip_device(curve, d_a.ptr, d_b.ptr, n, _ptr(out)))
+    return out
+
+
+def fold_scalars_device(curve, d_v, n_out, s_lo, s_hi, d_out=None):
+    d_out = d_out or d_v
+    _check(load().bpgpu_fold_scalars_device(curve, d_v.ptr, n_out, _ptr(_u64(s_lo)), _ptr(_u64(s_hi)), d_out.ptr))
+
+
+def fold_points_device(curve, d_g, n_out, s_lo, s_hi, d_out=None):
+    d_out = d_out or d_g
+    _check(load().bpgpu_fold_points_device(curve, d_g.ptr, n_out, _ptr(_u64(s_lo)), _ptr(_u64(s_hi)), d_out.ptr))
+
+
+def last_msm_timings():
+    out = (c_float * 8)()
+    _check(load().bpgpu_last_msm_timings(out))
+    return list(out)
+
+
+def measure_mad_peak():
+    v = c_double()
+    _check(load().bpgpu_measure_mad_peak(ctypes.byref(v)))
+    return v.value
+
+
+class IpaSession:
+    """Device-resident prover state for Bp::prove (reference src/proofs/bp_iter.rs:49-128)."""
+
+    def __init__(self, curve, a_gens_xyz, b_gens_xyz, ip_gen_xyz, a, b):
+        A, B = _u64(a_gens_xyz, 12), _u64(b_gens_xyz, 12)
+        q = _u64(ip_gen_xyz, 12)
+        a, b = _u64(a, 4), _u64(b, 4)
+        n = len(a)
+        assert len(A) == len(B) == len(b) == n
+        h = c_void_p()
+        _check(load().bpgpu_ipa_begin(curve, _ptr(A), _ptr(B), _ptr(q), _ptr(a), _ptr(b), n, ctypes.byref(h)))
+        self.h = h.value
+        self.curve = curve
+
+    def __len__(self):
+        return load().bpgpu_ipa_len(self.h)
+
+    def round_lr(self):
+        l, r = np.zeros(9, dtype=np.uint64), np.zeros(9, dtype=np.uint64)
+        _check(load().bpgpu_ipa_round_lr(self.h, _ptr(l), _ptr(r)))
+        return l, r
+
+    def round_fold(self, x, x_inv):
+        _check(load().bpgpu_ipa_round_fold(self.h, _ptr(_u64(x)), _ptr(_u64(x_inv))))
+
+    def finish(self):
+        fa, fb = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        _check(load().bpgpu_ipa_finish(self.h, _ptr(fa), _ptr(fb)))
+        return fa, fb
+
+    def export(self):
+        n = len(self)
+        A, B = np.zeros((n, 12), dtype=np.uint64), np.zeros((n, 12), dtype=np.uint64)
+        a, b = np.zeros((n, 4), dtype=np.uint64), np.zeros((n, 4), dtype=np.uint64)
+        _check(load().bpgpu_ipa_export(self.h, _ptr(A), _ptr(B), _ptr(a), _ptr(b)))
+        return A, B, a, b
+
+    def free(self):
+        if self.h:
+            load().bpgpu_ipa_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

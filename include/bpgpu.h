@@ -1,0 +1,154 @@
+/* bpgpu -- C ABI of the MI355X (gfx950) backend for the MSM + IPA-folding hot path of
+ * alex-ozdemir/bulletproofs (`ark-bp`).
+ *
+ * These are the entry points the reference's FFI shim for this path binds (see
+ * INTEGRATION.md for the Rust `extern "C"` block and the call sites it replaces).
+ * Plain pointers and sizes only; no exceptions cross the boundary; every function
+ * returns 0 on success and a negative BPGPU_E_* code on failure, after which
+ * bpgpu_last_error() describes it (the shim turns that into `panic!`, the
+ * reference's only error convention on this path).
+ *
+ * Data formats (all little-endian 64-bit limbs, exactly ark-ff 0.3's in-memory
+ * Fp256 = value * 2^256 mod p, canonical):
+ *   scalar            : 4 x u64                       (32 B)
+ *   jacobian point    : X[4] Y[4] Z[4], Z = 0 identity (96 B)   ark GroupProjective
+ *   affine point      : x[4] y[4], (0,0) = identity    (64 B)
+ *   result "xy_inf"   : x[4] y[4] inf, inf = 1 for the identity (72 B, x=y=0 then)
+ * curve: 0 = Pallas, 1 = Vesta.
+ *
+ * Results are group elements in *normalised* (affine) form: the shim rebuilds
+ * Projective { x, y, z: 1 } (or zero()), see SURVEY.md section 0.3.
+ *
+ * Threading: callable from any host thread; calls on one device are serialised
+ * by an internal mutex (the reference never calls msm concurrently).
+ * Ownership: the caller owns every buffer it passes; the library copies.
+ */
+#ifndef BPGPU_H
+#define BPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPGPU_OK 0
+#define BPGPU_E_ARG (-1)      /* bad argument (curve id, null pointer, size) */
+#define BPGPU_E_HIP (-2)      /* a HIP runtime call failed */
+#define BPGPU_E_NOINIT (-3)   /* bpgpu_init has not succeeded in this process */
+#define BPGPU_E_STATE (-4)    /* session call in the wrong state */
+
+#define BPGPU_PALLAS 0
+#define BPGPU_VESTA 1
+
+/* Create (or reuse) the context on HIP device `device` and make it current for the
+ * process.  Idempotent.  Replaces nothing in the reference (it has no device). */
+int bpgpu_init(int device);
+void bpgpu_shutdown(void);
+const char* bpgpu_last_error(void);
+/* MSM window width override for tuning (0 = automatic).  */
+int bpgpu_set_window_bits(int c);
+
+/* ---- variable-base MSM ------------------------------------------------------
+ * Replaces `pippenger_msm` (= `crate::util::msm`), reference src/util/msm.rs:88-193
+ * (entry re-exported at src/util/mod.rs:15).  The shim zips the two iterators into
+ * contiguous buffers first (the reference's own `zip ... unzip`, msm.rs:94-97), so
+ * `n` is the zipped length.  Accepts Z != 1, identity points, scalars 0 and 1, n = 0
+ * (-> identity). */
+int bpgpu_msm(int curve, const uint64_t* points_xyz, const uint64_t* scalars, size_t n,
+              uint64_t out_xy_inf[9]);
+/* Same with 64-byte affine inputs (known-affine generators). */
+int bpgpu_msm_affine(int curve, const uint64_t* points_xy, const uint64_t* scalars, size_t n,
+                     uint64_t out_xy_inf[9]);
+
+/* ---- inner product ----------------------------------------------------------
+ * Replaces `ip`, reference src/util/mod.rs:17-23 (caller asserts equal length). */
+int bpgpu_ip(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);
+
+/* ---- scalar-vector fold -----------------------------------------------------
+ * out[i] = s_lo * v[i] + s_hi * v[i + n_out], i < n_out.  Replaces the map/collect at
+ * reference src/proofs/bp_iter.rs:88-95 == src/reductions/bp_2ary_step.rs:51-58
+ * (a: (s_lo, s_hi) = (x, x^-1); b: (x^-1, x)).  `out` may alias `v`. */
+int bpgpu_fold_scalars(int curve, const uint64_t* v, size_t n_out, const uint64_t s_lo[4],
+                       const uint64_t s_hi[4], uint64_t* out);
+
+/* ---- generator fold ---------------------------------------------------------
+ * out[i] = g[i] * s_lo + g[i + n_out] * s_hi.  Replaces reference
+ * src/proofs/bp_iter.rs:97-104 == src/reductions/bp_2ary_step.rs:60-67,106-113 ==
+ * src/relations/ipa.rs:54-63 (A: (x^-1, x); B: (x, x^-1)).  Inputs are jacobian
+ * (96 B); outputs are jacobian with Z = 1 (identity: (0, 1, 0)). */
+int bpgpu_fold_points(int curve, const uint64_t* g_xyz, size_t n_out, const uint64_t s_lo[4],
+                      const uint64_t s_hi[4], uint64_t* out_xyz);
+
+/* ---- device-resident variants ------------------------------------------------
+ * For callers that keep generators / witnesses in HBM (the fixed public parameters
+ * of the IPA).  Device pointers are plain `void*` obtained from bpgpu_dev_alloc (or
+ * any hipMalloc'd memory on the context's device).  Device point format ("dev
+ * affine", 64 B): x[8] y[8] u32 words, canonical value * 2^261 mod p, (0,0) =
+ * identity -- produced only by bpgpu_points_to_device.  Device scalars are in ark
+ * form (32 B), i.e. a plain upload of the host array. */
+int bpgpu_dev_alloc(size_t bytes, void** dptr);
+int bpgpu_dev_free(void* dptr);
+int bpgpu_dev_upload(void* dptr, const void* host, size_t bytes);
+int bpgpu_dev_download(void* host, const void* dptr, size_t bytes);
+/* fmt: 0 = jacobian 96 B, 1 = affine 64 B.  d_out receives n * 64 bytes. */
+int bpgpu_points_to_device(int curve, const uint64_t* points, size_t n, int fmt, void* d_out);
+/* d_points (n * 64 B dev affine) -> host jacobian Z=1 / (0,1,0) */
+int bpgpu_points_from_device(int curve, const void* d_points, size_t n, uint64_t* out_xyz);
+int bpgpu_msm_device(int curve, const void* d_points, const void* d_scalars, size_t n,
+                     uint64_t out_xy_inf[9]);
+int bpgpu_ip_device(int curve, const void* d_a, const void* d_b, size_t n, uint64_t out[4]);
+int bpgpu_fold_scalars_device(int curve, const void* d_v, size_t n_out, const uint64_t s_lo[4],
+                              const uint64_t s_hi[4], void* d_out);
+int bpgpu_fold_points_device(int curve, const void* d_g, size_t n_out, const uint64_t s_lo[4],
+                             const uint64_t s_hi[4], void* d_out);
+
+/* ---- device-resident IPA prover session -------------------------------------
+ * Lets `Bp::prove` (reference src/proofs/bp_iter.rs:49-128) keep a, b, A, B in HBM
+ * across its log2(N) rounds; Fiat-Shamir stays with the caller between
+ * `round_lr` and `round_fold`.  Inputs are the *unpadded* vectors; the session pads
+ * to a power of two with identity points / zero scalars exactly as
+ * zero_pad_to_two_power does (src/util/mod.rs:137-144, bp_iter.rs:59-62).
+ *
+ *   begin -> { round_lr -> round_fold } x log2(N') -> finish -> free
+ *
+ * round_lr computes (bp_iter.rs:68-81)
+ *   L = msm(A[n..] | B[..n] | Q,  a[..n] | b[n..] | <a[..n], b[n..]>)
+ *   R = msm(A[..n] | B[n..] | Q,  a[n..] | b[..n] | <a[n..], b[..n]>)
+ * round_fold(x, x_inv) applies bp_iter.rs:88-104.  export materialises the current
+ * (a_gens, b_gens, a, b) for `Bp2aryStep::prove`, which must return the folded
+ * instance (src/reductions/bp_2ary_step.rs:72-86). */
+typedef struct bpgpu_ipa bpgpu_ipa;
+int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz,
+                    const uint64_t* ip_gen_xyz, const uint64_t* a, const uint64_t* b, size_t n,
+                    bpgpu_ipa** out);
+/* current (padded) vector length; 1 when the loop is finished */
+size_t bpgpu_ipa_len(const bpgpu_ipa* s);
+int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9]);
+int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]);
+int bpgpu_ipa_finish(bpgpu_ipa* s, uint64_t final_a[4], uint64_t final_b[4]);
+int bpgpu_ipa_export(bpgpu_ipa* s, uint64_t* a_gens_xyz, uint64_t* b_gens_xyz, uint64_t* a,
+                     uint64_t* b);
+void bpgpu_ipa_free(bpgpu_ipa* s);
+
+/* ---- helpers for the sharded (multi-GPU) MSM ---------------------------------
+ * Each rank runs bpgpu_msm* on its contiguous point range; the per-rank results
+ * (72 B each) are gathered (RCCL all_gather, done by the host language) and summed
+ * here.  No reference counterpart (the reference is single-process). */
+int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t out_xy_inf[9]);
+
+/* ---- instrumentation ----------------------------------------------------------
+ * Duration in milliseconds of the GPU phases of the last bpgpu_msm* call on this
+ * thread's context, measured with HIP events on the library's stream:
+ * [0] digits+histogram, [1] scan, [2] scatter, [3] bucket accumulate, [4] fix-up,
+ * [5] bucket reduce, [6] host tail (wall), [7] total GPU. */
+int bpgpu_last_msm_timings(float out_ms[8]);
+/* Sustained v_mad_u64_u32 issue rate (lane-ops/s) measured by a register-only loop:
+ * the integer roofline bench.py prices the MSM against. */
+int bpgpu_measure_mad_peak(double* mads_per_sec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPGPU_H */

@@ -1,0 +1,140 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the
+big-integer oracle on the same seeded inputs.  Bit-exact (integer work)."""
+import numpy as np
+import pytest
+
+from oracle import pasta_model as pm
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CURVES = [pm.PALLAS, pm.VESTA]
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    from bulletproofs_amd import ffi as f
+    f.init(0)
+    yield f
+    f.set_window_bits(0)
+
+
+def edge_scalars(c):
+    r = c.r
+    return [0, 1, 2, r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, 1 << 15, (1 << 15) - 1, (1 << 16) + 1, (1 << 254) % r,
+            (1 << 253) - 1, 0x8000800080008000800080008000800080008000800080008000800080008000 % r,
+            0x7fff7fff7fff7fff7fff7fff7fff7fff7fff7fff7fff7fff7fff7fff7fff7fff % r]
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_ip_and_fold_scalars(ffi, c):
+    for n in [0, 1, 2, 3, 64, 257, 1000, 4096 + 17]:
+        a = H.rand_scalars(c, n, 11 + n)
+        b = H.rand_scalars(c, n, 12 + n)
+        if n >= 3:
+            a[0], b[0], a[1], b[2] = c.r - 1, c.r - 1, 0, 1
+        got = H.scalars_from_abi(c, ffi.ip(c.curve_id, H.scalars_abi(c, a), H.scalars_abi(c, b)))[0]
+        assert got == pm.ip(c, a, b), n
+    for n in [1, 2, 5, 64, 1000]:
+        v = H.rand_scalars(c, 2 * n, 21 + n)
+        v[0] = 0
+        v[-1] = c.r - 1
+        x = H.rand_scalars(c, 1, 5)[0]
+        xi = pow(x, -1, c.r)
+        got = H.scalars_from_abi(c, ffi.fold_scalars(c.curve_id, H.scalars_abi(c, v), H.scalar_abi(c, x), H.scalar_abi(c, xi)))
+        assert got == pm.fold_scalars(c, v, x, xi), n
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_msm_small(ffi, c):
+    cid = c.curve_id
+    for n in [0, 1, 2, 3, 31, 32, 33, 257]:
+        pts = H.rand_points(c, n, 100 + n)
+        xs = H.rand_scalars(c, n, 200 + n)
+        es = edge_scalars(c)
+        for i in range(min(n, len(es))):
+            xs[i] = es[i]
+        if n >= 33:
+            pts[5] = None                      # identity among the bases (zero padding, bp_iter.rs:59-62)
+            pts[7] = pts[6]                    # duplicate base
+            xs[7] = xs[6]                      # ... in the same buckets -> doubling inside a bucket
+            pts[9] = pm.aff_neg(c, pts[8])     # P and -P with equal scalars -> bucket cancels to identity
+            xs[9] = xs[8]
+        want = pm.jac_to_affine(c, pm.msm_pippenger(c, [pm.to_jac(p) for p in pts], xs))
+        got = H.xy_inf_to_affine(c, ffi.msm(cid, H.jac_abi(c, pts), H.scalars_abi(c, xs)))
+        assert got == want, n
+        got = H.xy_inf_to_affine(c, ffi.msm_affine(cid, H.aff_abi(c, pts), H.scalars_abi(c, xs)))
+        assert got == want, n
+
+
+def test_msm_window_sweep_and_jacobian_inputs(ffi):
+    c = pm.PALLAS
+    n = 300
+    pts = H.rand_points(c, n, 42)
+    xs = H.rand_scalars(c, n, 43)
+    # non-trivial Z: scale (x, y, 1) -> (x z^2, y z^3, z)
+    zs = H.rand_scalars(pm.VESTA, n, 44)  # Vesta's scalar field = Pallas' base field
+    jac = [(p[0] * z * z % c.q, p[1] * z * z * z % c.q, z) for p, z in zip(pts, zs)]
+    jac[3] = (5, 7, 0)  # identity with junk X, Y
+    pts[3] = None
+    want = pm.jac_to_affine(c, pm.msm_naive(c, [pm.to_jac(p) for p in pts], xs))
+    for bits in [0, 2, 3, 5, 8, 11, 13, 16]:
+        ffi.set_window_bits(bits)
+        got = H.xy_inf_to_affine(c, ffi.msm(0, H.jac_abi(c, jac), H.scalars_abi(c, xs)))
+        assert got == want, bits
+    ffi.set_window_bits(0)
+    # zip truncation (msm.rs:94-97) and all-zero scalars
+    got = H.xy_inf_to_affine(c, ffi.msm(0, H.jac_abi(c, pts), H.scalars_abi(c, xs[:10])))
+    assert got == pm.jac_to_affine(c, pm.msm_naive(c, [pm.to_jac(p) for p in pts[:10]], xs[:10]))
+    assert H.xy_inf_to_affine(c, ffi.msm(0, H.jac_abi(c, pts), H.scalars_abi(c, [0] * n))) is None
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_fold_points(ffi, c):
+    n = 37
+    g = H.rand_points(c, 2 * n, 77)
+    g[0] = None                     # padding on the low side
+    g[n + 1] = None                 # padding on the high side
+    g[2] = None
+    g[n + 2] = None                 # both identity
+    g[n + 3] = g[3]                 # P == Q
+    g[n + 4] = pm.aff_neg(c, g[4])  # P == -Q
+    x = H.rand_scalars(c, 1, 9)[0]
+    xi = pow(x, -1, c.r)
+    for s_lo, s_hi in [(xi, x), (x, xi), (1, c.r - 1), (0, 5), (3, 0), (0, 0), (c.r - 1, c.r - 1)]:
+        want = [pm.jac_to_affine(c, p) for p in pm.fold_points(c, [pm.to_jac(p) for p in g], s_lo, s_hi)]
+        out = ffi.fold_points(c.curve_id, H.jac_abi(c, g), H.scalar_abi(c, s_lo), H.scalar_abi(c, s_hi))
+        assert H.jac_from_abi(c, out) == want, (s_lo, s_hi)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 17, 5])
+def test_bp_prove_session(ffi, c, n):
+    """Bp::prove through the device-resident session vs the oracle's bp_prove: identical
+    ls, rs, challenges, final_a, final_b (reference test sizes, src/lib.rs:188,257)."""
+    rng = pm.test_rng()
+    inst, wit = pm.sample_ipa(c, rng, n)
+    fs_seed = rng.gen_bytes32()
+    want = pm.bp_prove(c, inst, wit, pm.FiatShamirRng(fs_seed))
+
+    fs = pm.FiatShamirRng(fs_seed)
+    sess = ffi.IpaSession(c.curve_id, H.jac_abi(c, inst.a_gens), H.jac_abi(c, inst.b_gens), H.jac_abi(c, [inst.ip_gen]),
+                          H.scalars_abi(c, wit.a), H.scalars_abi(c, wit.b))
+    ls, rs, challs = [], [], []
+    while len(sess) > 1:
+        l, r = sess.round_lr()
+        l, r = H.xy_inf_to_affine(c, l), H.xy_inf_to_affine(c, r)
+        ls.append(l)
+        rs.append(r)
+        fs.absorb(pm.point_bytes_normalised(l))
+        fs.absorb(pm.point_bytes_normalised(r))
+        x = fs.rand_scalar(c)
+        challs.append(x)
+        sess.round_fold(H.scalar_abi(c, x), H.scalar_abi(c, pow(x, -1, c.r)))
+    fa, fb = sess.finish()
+    A, B, a, b = sess.export()
+    sess.free()
+    assert ls == want.ls and rs == want.rs and challs == want.challenges
+    assert H.scalars_from_abi(c, fa)[0] == want.final_a and H.scalars_from_abi(c, fb)[0] == want.final_b
+    # the proof verifies (reference: bp_iter.rs:130-178)
+    assert pm.bp_verify(c, inst, want, pm.FiatShamirRng(fs_seed))
