@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: variable-base MSM over Pallas on MI355X (BASELINE.json metric
+"MSM points/sec"), one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W [--log2n 20] [--curve pallas]
+
+A "step" is one MSM of 2^log2n (point, scalar) pairs per rank over operands already
+resident in HBM (the IPA-relevant case: generators are fixed public parameters), result
+returned to the host as a normalised point.  With N > 1 every rank owns a contiguous
+point range (weak scaling: 2^log2n pairs per rank); each step ends with the one real
+exchange the sharded MSM has, an all_gather of the 72-byte partial results over
+RCCL/xGMI followed by their sum (bpgpu_points_sum).  Rank 0 prints ONE JSON line.
+
+Inputs are synthetic: curve points grown from the generator (-1, 2) by repeated
+generator-fold calls with seeded random multipliers (no oracle involved), scalars uniform
+in [0, 2^254).  The cpu_baseline leg (rank 0, N = 1 only) times oracle/pasta_oracle.c --
+a restatement of the reference's pippenger_msm -- on a bounded sample of the same bytes
+and checks the GPU result of that sample against it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MADS_PER_FIELD_MUL = 136   # 8-limb CIOS = 2*8^2 + 8 multiply-adds
+MULS_PER_MIXED_ADD = 11    # mixed Jacobian add
+
+
+def synth_points(ffi, curve, n, seed):
+    """n distinct curve points as (n, 12) u64 ark-form Jacobian (Z = 1), grown from the
+    generator by fold_points with random multipliers: V <- V ++ (a V + b roll(V))."""
+    rng = np.random.default_rng(seed)
+    p_mod = [0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001,
+             0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001][curve]
+    R = 1 << 256
+
+    def fe(v):
+        return np.frombuffer((v * R % p_mod).to_bytes(32, "little"), dtype=np.uint64)
+
+    V = np.concatenate([fe(p_mod - 1), fe(2), fe(1)]).reshape(1, 12).copy()
+
+    def rand_scalar():
+        s = rng.integers(0, 1 << 63, size=4, dtype=np.uint64)
+        s[3] &= np.uint64((1 << 61) - 1)
+        return s
+
+    while len(V) < n:
+        m = min(len(V), n - len(V))
+        g = np.concatenate([V[:m], np.roll(V, 1, axis=0)[:m]])
+        U = ffi.fold_points(curve, g, rand_scalar(), rand_scalar())
+        V = np.concatenate([V, U])
+    return V[:n]
+
+
+def synth_scalars(n, seed):
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    s[:, 3] &= np.uint64((1 << 62) - 1)  # < 2^254 < r: valid Montgomery limbs of a uniform element
+    return s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20, help="log2 of the points per rank")
+    ap.add_argument("--curve", default="pallas", choices=["pallas", "vesta"])
+    ap.add_argument("--window", type=int, default=0, help="override the MSM window width (0 = automatic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2n", type=int, default=17, help="log2 of the CPU-baseline sample size")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bulletproofs_amd import ffi
+    ffi.init(local_rank)
+    if args.window:
+        ffi.set_window_bits(args.window)
+    curve = 0 if args.curve == "pallas" else 1
+    n = 1 << args.log2n
+
+    pts = synth_points(ffi, curve, n, seed=1000 + rank)
+    sc = synth_scalars(n, seed=2000 + rank)
+    d_pts = ffi.points_to_device(curve, pts, fmt=0)
+    d_sc = ffi.scalars_to_device(sc)
+
+    gather_buf = [torch.zeros(9, dtype=torch.int64, device="cuda") for _ in range(world)] if world > 1 else None
+
+    def step():
+        part = ffi.msm_device(curve, d_pts, d_sc, n)
+        if world > 1:
+            mine = torch.from_numpy(part.view(np.int64)).cuda()
+            dist.all_gather(gather_buf, mine)
+            allp = torch.stack(gather_buf).cpu().numpy().view(np.uint64)
+            return ffi.points_sum(curve, allp), part
+        return part, part
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    phase = np.zeros(8)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result, part = step()
+        phase += np.array(ffi.last_msm_timings())
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    phase /= max(1, args.steps)
+
+    # PCIe-inclusive rate (host buffers in, like examples/msm_bench.rs:45-48), a few repetitions
+    h2h = None
+    if rank == 0:
+        reps = 3
+        ffi.msm(curve, pts, sc)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ffi.msm(curve, pts, sc)
+        h2h = (time.perf_counter() - t1) / reps
+
+    out = None
+    if rank == 0:
+        mad_peak = ffi.measure_mad_peak()
+        c_bits = args.window or max(2, min(16, args.log2n - 4))
+        W = (256 + c_bits - 1) // c_bits
+        accum_s = phase[3] * 1e-3
+        algo_mads = W * n * MULS_PER_MIXED_ADD * MADS_PER_FIELD_MUL
+        achieved = algo_mads / accum_s if accum_s > 0 else 0.0
+        out = {
+            "metric": "MSM points/sec (Pallas, variable-base)" if curve == 0 else "MSM points/sec (Vesta, variable-base)",
+            "value": world * n * args.steps / dt,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (255-bit Montgomery, 9x29-bit, int64 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": f"2^{args.log2n}-point {args.curve} MSM per GPU, operands resident in HBM",
+                       "points_per_gpu": n, "total_points": world * n, "window_bits": c_bits, "windows": W,
+                       "parallelism": f"point-range shards x{world}, all_gather of 72 B partials" if world > 1 else "single GPU"},
+            "roofline": {"bound": "valu", "kernel": "k_accum (bucket accumulation, mixed XYZZ adds)",
+                         "achieved": achieved / 1e12, "peak": mad_peak / 1e12, "unit": "Tmad/s",
+                         "frac": achieved / mad_peak if mad_peak else None, "traffic": None,
+                         "avg_kernel_ms": phase[3],
+                         "note": "algorithmic mads = windows * n * 11 field-mul * 136 mad (SURVEY 8d); peak = measured v_mad_u64_u32 issue rate"},
+            "phases_ms": {"digits+hist": phase[0], "scan": phase[1], "scatter": phase[2], "accumulate": phase[3],
+                          "reduce": phase[5], "host_tail": phase[6], "gpu_total": phase[7]},
+            "host_to_host": {"ms": h2h * 1e3, "points_per_s": n / h2h,
+                             "note": "host buffers in, PCIe + Jacobian->affine conversion included (msm_bench.rs:45-48 window)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ffi, curve, pts, sc, min(args.cpu_log2n, args.log2n))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ffi, curve, pts, sc, log2s):
+    """Oracle B (restatement of pippenger_msm, threads over windows like rayon at msm.rs:119)
+    on the first 2^log2s pairs of the bench inputs; the only place bench.py touches oracle/."""
+    import ctypes
+    from oracle import c_oracle as co
+    ns = 1 << log2s
+    threads = min(16, os.cpu_count() or 1)
+    co.load(threads)
+    t0 = time.perf_counter()
+    want = co.msm_pippenger(curve, pts[:ns], sc[:ns], threads=threads)
+    dt = time.perf_counter() - t0
+    got = ffi.msm(curve, pts[:ns], sc[:ns])
+    ok = (int(got[8]) == 0 and bool((got[:8] == want[:8]).all())) or (int(got[8]) == 1 and not want[8:].any())
+    t1 = time.perf_counter()
+    co.msm_pippenger(curve, pts[:ns], sc[:ns], threads=1) if log2s <= 15 else None
+    dt1 = time.perf_counter() - t1 if log2s <= 15 else None
+    return {"value": ns / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"first 2^{log2s} pairs of the bench inputs, window c={co.load(threads).po_pippenger_window(ctypes.c_size_t(ns))}, {dt:.2f} s",
+            "single_thread_points_per_s": (ns / dt1) if dt1 else None,
+            "gpu_matches_cpu_on_sample": bool(ok)}
+
+
+if __name__ == "__main__":
+    main()
