@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--curve", default="pallas", choices=["pallas", "vesta"])
     ap.add_argument("--window", type=int, default=0, help="override the MSM window width (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2n", type=int, default=17, help="log2 of the CPU-baseline sample size")
+    ap.add_argument("--cpu-log2n", type=int, default=20, help="log2 of the CPU-baseline sample size")
     args = ap.parse_args()
 
     import torch
@@ -103,16 +103,12 @@ def main():
     d_pts = ffi.points_to_device(curve, pts, fmt=0)
     d_sc = ffi.scalars_to_device(sc)
 
-    gather_buf = [torch.zeros(9, dtype=torch.int64, device="cuda") for _ in range(world)] if world > 1 else None
+    from bulletproofs_amd import sharded
+    dev = torch.device("cuda", local_rank)
 
     def step():
         part = ffi.msm_device(curve, d_pts, d_sc, n)
-        if world > 1:
-            mine = torch.from_numpy(part.view(np.int64)).cuda()
-            dist.all_gather(gather_buf, mine)
-            allp = torch.stack(gather_buf).cpu().numpy().view(np.uint64)
-            return ffi.points_sum(curve, allp), part
-        return part, part
+        return sharded.combine_partials(curve, part, dev), part
 
     def sync():
         if world > 1:
