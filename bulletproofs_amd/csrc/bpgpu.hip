@@ -75,7 +75,7 @@ struct Ctx {
   int window_bits = 0;
   float msm_ms[8] = {};
   // MSM workspace (grow-only)
-  DevBuf counts, offs, cursor, sorted, bsum, partial, winsum;
+  DevBuf counts, offs, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum;
   // staging for host-buffer entry points
   DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
   std::vector<uint32_t> h_winsum;
@@ -164,23 +164,40 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const uint32_t nruns = NB >> s;
   const uint32_t runs_per_window = B >> s;
 
-  TRY(C.counts.ensure((size_t)(NB + 1) * 4));
+  // two-level counting sort: coarse bins of 2^fine_bits buckets
+  SortPlan sp;
+  sp.fine_bits = c - 1 < 10 ? c - 1 : 10;
+  sp.nbins = NB >> sp.fine_bits;
+  sp.tiles = cdiv(slots, 1024);
+  const uint32_t part_grid = sp.tiles < 512 ? sp.tiles : 512;
+  const size_t lds_bytes = (size_t)sp.nbins * 8;
+  if (lds_bytes > 64 * 1024) return fail(BPGPU_E_ARG, "window width %d needs %zu B of LDS bin counters", c, lds_bytes);
+
+  TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2));  // bin_count | bin_cursor
+  TRY(C.cursor.ensure((size_t)(sp.nbins + 1) * 4));          // bin_start
   TRY(C.offs.ensure((size_t)(NB + 1) * 4));
-  TRY(C.cursor.ensure((size_t)(NB + 1) * 4));
+  TRY(C.canon.ensure((size_t)slots * 32));
+  TRY(C.ent_idx.ensure((size_t)slots * W * 4 + 4));
+  TRY(C.ent_fine.ensure((size_t)slots * W * 2 + 4));
   TRY(C.sorted.ensure((size_t)slots * W * 4 + 4));
   TRY(C.bsum.ensure((size_t)NB * 128));
   TRY(C.partial.ensure((size_t)nruns * 128));
   TRY(C.winsum.ensure((size_t)plan.M * W * 128));
+  uint32_t* bin_count = C.counts.as<uint32_t>();
+  uint32_t* bin_cursor = bin_count + (size_t)sp.nbins * BIN_PAD;
+  uint32_t* bin_start = C.cursor.as<uint32_t>();
 
   hipStream_t st = C.stream;
   HIP_TRY(hipEventRecord(C.ev[0], st));
-  HIP_TRY(hipMemsetAsync(C.counts.p, 0, (size_t)(NB + 1) * 4, st));
-  k_digits<SF, 0><<<cdiv(slots, 256), 256, 0, st>>>(plan, d_scalars, C.counts.as<uint32_t>(), nullptr);
+  HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4, st));
+  k_part_count<SF><<<part_grid, 1024, lds_bytes, st>>>(plan, sp, d_scalars, C.canon.as<uint32_t>(), bin_count);
   HIP_TRY(hipEventRecord(C.ev[1], st));
-  k_scan<<<1, 1024, 0, st>>>(C.counts.as<uint32_t>(), C.offs.as<uint32_t>(), C.cursor.as<uint32_t>(), NB);
+  k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, bin_cursor, sp.nbins);
+  k_part_scatter<<<part_grid, 1024, lds_bytes, st>>>(plan, sp, C.canon.as<uint32_t>(), bin_start, bin_cursor,
+                                                     C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>());
   HIP_TRY(hipEventRecord(C.ev[2], st));
-  k_digits<SF, 1><<<cdiv(slots, 256), 256, 0, st>>>(plan, d_scalars, C.cursor.as<uint32_t>(),
-                                                       C.sorted.as<uint32_t>());
+  k_bin_sort<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
+                                        C.sorted.as<uint32_t>(), C.offs.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[3], st));
   k_accum<BF><<<cdiv(NB, 128), 128, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
                                              C.bsum.as<uint32_t>(), NB);
@@ -401,7 +418,7 @@ void bpgpu_shutdown(void) {
   if (!g_ctx.ready) return;
   (void)hipSetDevice(g_ctx.device);
   (void)hipStreamSynchronize(g_ctx.stream);
-  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.cursor, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial,
+  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial,
                     &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip})
     b->release();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);

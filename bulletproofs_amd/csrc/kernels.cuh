@@ -2,9 +2,9 @@
 // bpgpu.hip; arithmetic is in field.cuh / curve.cuh.
 //
 // MSM pipeline (reference algorithm being replaced: pippenger_msm, src/util/msm.rs:88-193):
-//   k_digits<HIST>   scalar -> canonical -> signed c-bit digits; per-bucket histogram
-//   k_scan           exclusive prefix sum over all M*W*B bucket counts
-//   k_digits<SCAT>   same digits again; scatter point indices into bucket-sorted order
+//   k_part_count / k_bin_scan / k_part_scatter / k_bin_sort
+//                    scalar -> canonical -> signed c-bit digits; two-level counting sort of
+//                    the (point, window) pairs by bucket (LDS histograms, see below)
 //   k_accum          one lane per bucket: mixed additions of its points (XYZZ accumulator)
 //   k_reduce1        one lane per run of S buckets: running-sum reduction (msm.rs:167-171)
 //   k_reduce2        one workgroup per window: tree-sum of the run results
@@ -40,59 +40,93 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t (&w)[8], int pos
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 
-// SF = scalar field id.  MODE 0: histogram; MODE 1: scatter.
-template <int SF, int MODE>
-__global__ void __launch_bounds__(256) k_digits(MsmPlan plan, const uint32_t* __restrict__ scalars,
-                                                uint32_t* __restrict__ counts,  // hist (MODE 0) / cursor (MODE 1)
-                                                uint32_t* __restrict__ sorted) {
-  using F = Fp<SF>;
-  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (uint64_t)plan.M * plan.n) return;
-  int m = (int)(gid / plan.n);
+// ---------------------------------------------------------------------------
+// Bucket sort of the (point, window) pairs: a two-level counting sort whose only global
+// atomics are one per (workgroup, coarse bin).
+//   bucket id  = (m*W + j) << (c-1) | (|digit| - 1)              (global, over all windows)
+//   coarse bin = bucket id >> fine_bits,  fine = bucket id & (2^fine_bits - 1)
+//   k_part_count    digits -> per-workgroup LDS histogram of coarse bins -> bin_count
+//   k_bin_scan      exclusive scan of the bin counts (one small workgroup)
+//   k_part_scatter  digits again -> (index|sign, fine) entries appended to their bin
+//   k_bin_sort      one workgroup per bin: LDS counting sort by fine bucket -> sorted[], offs[]
+// ---------------------------------------------------------------------------
+struct SortPlan {
+  int fine_bits;       // buckets per bin = 2^fine_bits (<= 1024)
+  uint32_t nbins;      // M * W << (c - 1 - fine_bits)
+  uint32_t tiles;      // number of 1024-slot tiles = ceil(M*n / 1024)
+};
+constexpr int BIN_PAD = 16;  // bin counters live 64 B apart (one per L2 line)
+
+// slot -> (point index, scalar index); returns false past the end
+__device__ __forceinline__ bool slot_lookup(const MsmPlan& plan, uint64_t gid, int& m, uint32_t& pt_idx,
+                                            uint32_t& sc_idx) {
+  if (gid >= (uint64_t)plan.M * plan.n) return false;
+  m = (int)(gid / plan.n);
   uint32_t t = (uint32_t)(gid % plan.n);
   int s = 0;
   while (s < 2 && t >= plan.seg[m][s].count) {
     t -= plan.seg[m][s].count;
     s++;
   }
-  uint32_t pt_idx = plan.seg[m][s].pt_off + t;
-  const uint32_t* sp = scalars + 8ull * (plan.seg[m][s].sc_off + t);
-  uint32_t w[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) w[i] = sp[i];
-  // ark form s*2^256  ->  canonical s   (into_repr at msm.rs:96)
-  Fe v = F::mul(F::unpack(w), F::from_const(F::C::C256TOCANON));
-  F::pack(F::canon(v), w);
-  const int c = plan.c;
+  pt_idx = plan.seg[m][s].pt_off + t;
+  sc_idx = plan.seg[m][s].sc_off + t;
+  return true;
+}
+
+// calls f(bucket_id, neg) for every non-zero signed digit of the canonical scalar w
+template <class Fn>
+__device__ __forceinline__ void for_each_digit(const uint32_t (&w)[8], int m, int W, int c, Fn f) {
   const uint32_t half = 1u << (c - 1);
   uint32_t carry = 0;
-  for (int j = 0; j < plan.W; j++) {
+  for (int j = 0; j < W; j++) {
     uint32_t bits = extract_bits(w, j * c, c) + carry;
     uint32_t neg = bits > half ? 1u : 0u;
     uint32_t mag = neg ? (1u << c) - bits : bits;
     carry = neg;
-    if (mag != 0) {
-      uint32_t key = ((uint32_t)(m * plan.W + j) << (c - 1)) + (mag - 1);
-      if (MODE == 0) {
-        atomicAdd(&counts[key], 1u);
-      } else {
-        uint32_t pos = atomicAdd(&counts[key], 1u);
-        sorted[pos] = pt_idx | (neg << 31);
-      }
-    }
+    if (mag != 0) f(((uint32_t)(m * W + j) << (c - 1)) + (mag - 1), neg);
   }
 }
 
-// Exclusive prefix sum of counts[0..n) into offs[0..n] (offs[n] = total) and a copy
-// into cursor[0..n).  One workgroup; n is at most a few million.
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs,
-                                               uint32_t* __restrict__ cursor, uint32_t n) {
+// SF = scalar field id.  Also stores the canonical scalars (into_repr, msm.rs:96) for the scatter pass.
+template <int SF>
+__global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, const uint32_t* __restrict__ scalars,
+                                                     uint32_t* __restrict__ canon, uint32_t* __restrict__ bin_count) {
+  using F = Fp<SF>;
+  extern __shared__ uint32_t lds[];
+  uint32_t* cnt = lds;
+  for (uint32_t b = threadIdx.x; b < sp.nbins; b += 1024) cnt[b] = 0;
+  __syncthreads();
+  for (uint32_t tile = blockIdx.x; tile < sp.tiles; tile += gridDim.x) {
+    uint64_t gid = (uint64_t)tile * 1024 + threadIdx.x;
+    int m;
+    uint32_t pt_idx, sc_idx;
+    if (!slot_lookup(plan, gid, m, pt_idx, sc_idx)) continue;
+    const uint4* sp4 = reinterpret_cast<const uint4*>(scalars + 8ull * sc_idx);
+    uint4 lo = sp4[0], hi = sp4[1];
+    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    Fe v = F::mul(F::unpack(w), F::from_const(F::C::C256TOCANON));
+    F::pack(F::canon(v), w);
+    uint4* cp = reinterpret_cast<uint4*>(canon + 8ull * gid);
+    cp[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    cp[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    for_each_digit(w, m, plan.W, plan.c, [&](uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> sp.fine_bits], 1u); });
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < sp.nbins; b += 1024) {
+    uint32_t v = cnt[b];
+    if (v) atomicAdd(&bin_count[(uint64_t)b * BIN_PAD], v);
+  }
+}
+
+// bin_start[0..nbins] = exclusive scan of bin_count; zeroes bin_cursor.  One workgroup.
+__global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t* __restrict__ bin_count, uint32_t* __restrict__ bin_start,
+                                                   uint32_t* __restrict__ bin_cursor, uint32_t nbins) {
   __shared__ uint32_t part[1024];
   uint32_t tid = threadIdx.x;
-  uint32_t per = (n + 1023) / 1024;
-  uint32_t lo = tid * per, hi = min(lo + per, n);
+  uint32_t per = (nbins + 1023) / 1024;
+  uint32_t lo = min(tid * per, nbins), hi = min(lo + per, nbins);
   uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += counts[i];
+  for (uint32_t i = lo; i < hi; i++) s += bin_count[(uint64_t)i * BIN_PAD];
   part[tid] = s;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -103,11 +137,91 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
   }
   uint32_t run = part[tid] - s;
   for (uint32_t i = lo; i < hi; i++) {
-    offs[i] = run;
-    cursor[i] = run;
-    run += counts[i];
+    bin_start[i] = run;
+    bin_cursor[(uint64_t)i * BIN_PAD] = 0;
+    run += bin_count[(uint64_t)i * BIN_PAD];
   }
-  if (tid == 1023) offs[n] = part[1023];
+  if (tid == 1023) bin_start[nbins] = part[1023];
+}
+
+__global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp, const uint32_t* __restrict__ canon,
+                                                       const uint32_t* __restrict__ bin_start,
+                                                       uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ ent_idx,
+                                                       uint16_t* __restrict__ ent_fine) {
+  extern __shared__ uint32_t lds[];
+  uint32_t* cnt = lds;
+  uint32_t* cur = lds + sp.nbins;
+  const uint32_t fine_mask = (1u << sp.fine_bits) - 1u;
+  for (uint32_t b = threadIdx.x; b < sp.nbins; b += 1024) cnt[b] = 0;
+  __syncthreads();
+  // sweep A: this workgroup's bin counts
+  for (uint32_t tile = blockIdx.x; tile < sp.tiles; tile += gridDim.x) {
+    uint64_t gid = (uint64_t)tile * 1024 + threadIdx.x;
+    int m;
+    uint32_t pt_idx, sc_idx;
+    if (!slot_lookup(plan, gid, m, pt_idx, sc_idx)) continue;
+    const uint4* cp = reinterpret_cast<const uint4*>(canon + 8ull * gid);
+    uint4 lo = cp[0], hi = cp[1];
+    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for_each_digit(w, m, plan.W, plan.c, [&](uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> sp.fine_bits], 1u); });
+  }
+  __syncthreads();
+  // reserve this workgroup's slice of every bin
+  for (uint32_t b = threadIdx.x; b < sp.nbins; b += 1024) {
+    uint32_t v = cnt[b];
+    cur[b] = bin_start[b] + (v ? atomicAdd(&bin_cursor[(uint64_t)b * BIN_PAD], v) : 0u);
+  }
+  __syncthreads();
+  // sweep B: append the entries
+  for (uint32_t tile = blockIdx.x; tile < sp.tiles; tile += gridDim.x) {
+    uint64_t gid = (uint64_t)tile * 1024 + threadIdx.x;
+    int m;
+    uint32_t pt_idx, sc_idx;
+    if (!slot_lookup(plan, gid, m, pt_idx, sc_idx)) continue;
+    const uint4* cp = reinterpret_cast<const uint4*>(canon + 8ull * gid);
+    uint4 lo = cp[0], hi = cp[1];
+    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for_each_digit(w, m, plan.W, plan.c, [&](uint32_t bucket, uint32_t neg) {
+      uint32_t pos = atomicAdd(&cur[bucket >> sp.fine_bits], 1u);
+      ent_idx[pos] = pt_idx | (neg << 31);
+      ent_fine[pos] = (uint16_t)(bucket & fine_mask);
+    });
+  }
+}
+
+// One workgroup per coarse bin: counting sort of its entries by fine bucket, all counters in LDS.
+// Writes sorted[] (point index | sign) and the bucket offsets offs[bucket] (offs[nbuckets] = total).
+__global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* __restrict__ bin_start,
+                                                   const uint32_t* __restrict__ ent_idx,
+                                                   const uint16_t* __restrict__ ent_fine, uint32_t* __restrict__ sorted,
+                                                   uint32_t* __restrict__ offs) {
+  __shared__ uint32_t cnt[1024];
+  __shared__ uint32_t part[1024];
+  const uint32_t bin = blockIdx.x, tid = threadIdx.x;
+  const uint32_t F = 1u << sp.fine_bits;
+  const uint32_t bs = bin_start[bin], be = bin_start[bin + 1];
+  cnt[tid] = 0;
+  __syncthreads();
+  for (uint32_t e = bs + tid; e < be; e += 1024) atomicAdd(&cnt[ent_fine[e]], 1u);
+  __syncthreads();
+  uint32_t mine = cnt[tid];
+  part[tid] = mine;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t start = bs + part[tid] - mine;
+  if (tid < F) offs[(uint64_t)bin * F + tid] = start;
+  if (bin == gridDim.x - 1 && tid == 0) offs[(uint64_t)gridDim.x * F] = be;
+  cnt[tid] = start;  // becomes the write cursor
+  __syncthreads();
+  for (uint32_t e = bs + tid; e < be; e += 1024) {
+    uint32_t pos = atomicAdd(&cnt[ent_fine[e]], 1u);
+    sorted[pos] = ent_idx[e];
+  }
 }
 
 // One lane per bucket.  BF = base field id.
