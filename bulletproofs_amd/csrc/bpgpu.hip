@@ -75,7 +75,7 @@ struct Ctx {
   int window_bits = 0;
   float msm_ms[8] = {};
   // MSM workspace (grow-only)
-  DevBuf counts, offs, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum;
+  DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum;
   // staging for host-buffer entry points
   DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
   std::vector<uint32_t> h_winsum;
@@ -176,6 +176,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2));  // bin_count | bin_cursor
   TRY(C.cursor.ensure((size_t)(sp.nbins + 1) * 4));          // bin_start
   TRY(C.offs.ensure((size_t)(NB + 1) * 4));
+  TRY(C.order.ensure((size_t)NB * 4));
   TRY(C.canon.ensure((size_t)slots * 32));
   TRY(C.ent_idx.ensure((size_t)slots * W * 4 + 4));
   TRY(C.ent_fine.ensure((size_t)slots * W * 2 + 4));
@@ -197,10 +198,10 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
                                                      C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>());
   HIP_TRY(hipEventRecord(C.ev[2], st));
   k_bin_sort<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
-                                        C.sorted.as<uint32_t>(), C.offs.as<uint32_t>());
+                                        C.sorted.as<uint32_t>(), C.offs.as<uint32_t>(), C.order.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[3], st));
-  k_accum<BF><<<cdiv(NB, 128), 128, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
-                                             C.bsum.as<uint32_t>(), NB);
+  k_accum<BF><<<cdiv(NB, 64), 64, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
+                                           C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB);
   HIP_TRY(hipEventRecord(C.ev[4], st));
   k_reduce1<BF><<<cdiv(nruns, 64), 64, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s, c - 1);
   k_reduce2<BF><<<plan.M * W, 256, 0, st>>>(C.partial.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window);
@@ -418,7 +419,7 @@ void bpgpu_shutdown(void) {
   if (!g_ctx.ready) return;
   (void)hipSetDevice(g_ctx.device);
   (void)hipStreamSynchronize(g_ctx.stream);
-  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial,
+  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial,
                     &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip})
     b->release();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);

@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
 __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* __restrict__ bin_start,
                                                    const uint32_t* __restrict__ ent_idx,
                                                    const uint16_t* __restrict__ ent_fine, uint32_t* __restrict__ sorted,
-                                                   uint32_t* __restrict__ offs) {
+                                                   uint32_t* __restrict__ offs, uint32_t* __restrict__ order) {
   __shared__ uint32_t cnt[1024];
   __shared__ uint32_t part[1024];
   const uint32_t bin = blockIdx.x, tid = threadIdx.x;
@@ -218,6 +218,33 @@ __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* 
   if (bin == gridDim.x - 1 && tid == 0) offs[(uint64_t)gridDim.x * F] = be;
   cnt[tid] = start;  // becomes the write cursor
   __syncthreads();
+  // order[]: this bin's buckets by decreasing size, so that the 64 lanes of a k_accum wave
+  // walk lists of (nearly) equal length
+  {
+    const uint32_t key = 255u - (mine < 255u ? mine : 255u);
+    part[tid] = 0;
+    __syncthreads();
+    if (tid < F) atomicAdd(&part[key], 1u);
+    __syncthreads();
+    uint32_t h = tid < 256 ? part[tid] : 0;
+    __syncthreads();
+    part[tid] = h;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+      uint32_t v = (tid >= d && tid < 256) ? part[tid - d] : 0;
+      __syncthreads();
+      if (tid < 256) part[tid] += v;
+      __syncthreads();
+    }
+    uint32_t excl = tid < 256 ? part[tid] - h : 0;
+    __syncthreads();
+    if (tid < 256) part[tid] = excl;
+    __syncthreads();
+    if (tid < F) {
+      uint32_t pos = atomicAdd(&part[key], 1u);
+      order[(uint64_t)bin * F + pos] = bin * F + tid;
+    }
+  }
   for (uint32_t e = bs + tid; e < be; e += 1024) {
     uint32_t pos = atomicAdd(&cnt[ent_fine[e]], 1u);
     sorted[pos] = ent_idx[e];
@@ -227,12 +254,13 @@ __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* 
 // One lane per bucket.  BF = base field id.
 template <int BF>
 __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
-                                               const uint32_t* __restrict__ sorted, uint32_t* __restrict__ bsum,
-                                               uint32_t nbuckets) {
+                                               const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
+                                               uint32_t* __restrict__ bsum, uint32_t nbuckets) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbuckets) return;
+  uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= nbuckets) return;
+  uint32_t b = order[gid];
   uint32_t lo = offs[b], hi = offs[b + 1];
   Xyzz acc = E::identity();
   for (uint32_t e = lo; e < hi; e++) {
