@@ -73,6 +73,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
   int window_bits = 0;
+  int num_cus = 256;
   float msm_ms[8] = {};
   // MSM workspace (grow-only)
   DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum;
@@ -173,7 +174,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const size_t lds_bytes = (size_t)sp.nbins * 8;
   if (lds_bytes > 64 * 1024) return fail(BPGPU_E_ARG, "window width %d needs %zu B of LDS bin counters", c, lds_bytes);
 
-  TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2));  // bin_count | bin_cursor
+  TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2 + 64));  // bin_count | chunk counter | bin_cursor
   TRY(C.cursor.ensure((size_t)(sp.nbins + 1) * 4));          // bin_start
   TRY(C.offs.ensure((size_t)(NB + 1) * 4));
   TRY(C.order.ensure((size_t)NB * 4));
@@ -185,12 +186,13 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   TRY(C.partial.ensure((size_t)nruns * 128));
   TRY(C.winsum.ensure((size_t)plan.M * W * 128));
   uint32_t* bin_count = C.counts.as<uint32_t>();
-  uint32_t* bin_cursor = bin_count + (size_t)sp.nbins * BIN_PAD;
+  uint32_t* chunk_counter = bin_count + (size_t)sp.nbins * BIN_PAD;  // zeroed with bin_count
+  uint32_t* bin_cursor = chunk_counter + 16;
   uint32_t* bin_start = C.cursor.as<uint32_t>();
 
   hipStream_t st = C.stream;
   HIP_TRY(hipEventRecord(C.ev[0], st));
-  HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4, st));
+  HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4 + 64, st));
   k_part_count<SF><<<part_grid, 1024, lds_bytes, st>>>(plan, sp, d_scalars, C.canon.as<uint32_t>(), bin_count);
   HIP_TRY(hipEventRecord(C.ev[1], st));
   k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, bin_cursor, sp.nbins);
@@ -200,8 +202,9 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   k_bin_sort<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
                                         C.sorted.as<uint32_t>(), C.offs.as<uint32_t>(), C.order.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[3], st));
-  k_accum<BF><<<cdiv(NB, 64), 64, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
-                                           C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB);
+  k_accum<BF><<<C.num_cus * 3, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
+                                             C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits,
+                                             chunk_counter);
   HIP_TRY(hipEventRecord(C.ev[4], st));
   k_reduce1<BF><<<cdiv(nruns, 64), 64, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s, c - 1);
   k_reduce2<BF><<<plan.M * W, 256, 0, st>>>(C.partial.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window);
@@ -409,6 +412,9 @@ int bpgpu_init(int device) {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
   for (auto& e : g_ctx.ev) HIP_TRY(hipEventCreate(&e));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  g_ctx.num_cus = prop.multiProcessorCount;
   g_ctx.device = device;
   g_ctx.ready = true;
   return 0;

@@ -32,8 +32,14 @@
 #if defined(__HIPCC__)
 #define BP_HD __host__ __device__ __forceinline__
 #define BP_UNROLL _Pragma("unroll")
+#if defined(BP_NOINLINE_MUL)
+#define BP_MUL __host__ __device__ __attribute__((noinline))
+#else
+#define BP_MUL BP_HD
+#endif
 #else
 #define BP_HD inline
+#define BP_MUL inline
 #define BP_UNROLL
 #endif
 
@@ -158,7 +164,7 @@ struct Fp {
     return r;
   }
 
-  static BP_HD Fe mul(const Fe& a, const Fe& b) {
+  static BP_MUL Fe mul(const Fe& a, const Fe& b) {
     acc_t t[18];
     BP_UNROLL
     for (int k = 0; k < 18; k++) t[k] = 0;
@@ -173,7 +179,7 @@ struct Fp {
     return redc(t);
   }
 
-  static BP_HD Fe sqr(const Fe& a) {
+  static BP_MUL Fe sqr(const Fe& a) {
     acc_t t[18];
     BP_UNROLL
     for (int k = 0; k < 18; k++) t[k] = 0;

@@ -251,25 +251,46 @@ __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* 
   }
 }
 
-// One lane per bucket.  BF = base field id.
+// Bucket accumulation.  BF = base field id.  Persistent waves: the grid is sized to the chip
+// (3 waves per SIMD) and every wave pulls chunks of 64 buckets from a shared counter until
+// none is left (each wave reaches chunk >= nchunks and leaves).  Chunks are handed out largest
+// first: chunk k is the (k / nbins)-th group of 64 buckets, in decreasing size, of bin
+// k % nbins (k_bin_sort's order[]), so lanes of a wave walk lists of near-equal length and the
+// kernel's tail is made of the shortest lists.
 template <int BF>
 __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
                                                const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
-                                               uint32_t* __restrict__ bsum, uint32_t nbuckets) {
+                                               uint32_t* __restrict__ bsum, uint32_t nbuckets, uint32_t nbins,
+                                               int fine_bits, uint32_t* __restrict__ chunk_counter) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
-  uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= nbuckets) return;
-  uint32_t b = order[gid];
-  uint32_t lo = offs[b], hi = offs[b + 1];
-  Xyzz acc = E::identity();
-  for (uint32_t e = lo; e < hi; e++) {
-    uint32_t ent = sorted[e];
-    Aff q = IO::load_dev_affine(points + 16ull * (ent & 0x7fffffffu));
-    if (ent >> 31) q = E::neg(q);
-    E::madd(acc, q);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t nchunks = (nbuckets + 63u) >> 6;
+  const uint32_t F = 1u << fine_bits;
+  for (;;) {
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(chunk_counter, 1u);
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k >= nchunks) break;
+    uint32_t gid;
+    if (F >= 64u) {
+      uint32_t pos = k / nbins, bin = k - pos * nbins;
+      gid = bin * F + pos * 64u + lane;
+    } else {
+      gid = k * 64u + lane;
+    }
+    if (gid >= nbuckets) continue;
+    uint32_t b = order[gid];
+    uint32_t lo = offs[b], hi = offs[b + 1];
+    Xyzz acc = E::identity();
+    for (uint32_t e = lo; e < hi; e++) {
+      uint32_t ent = sorted[e];
+      Aff q = IO::load_dev_affine(points + 16ull * (ent & 0x7fffffffu));
+      if (ent >> 31) q = E::neg(q);
+      E::madd(acc, q);
+    }
+    IO::store_dev_xyzz(bsum + 32ull * b, acc);
   }
-  IO::store_dev_xyzz(bsum + 32ull * b, acc);
 }
 
 // One lane per run of S = 2^s consecutive buckets of one window.  With k0 the
