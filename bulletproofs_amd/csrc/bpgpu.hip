@@ -202,7 +202,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   k_bin_sort<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
                                         C.sorted.as<uint32_t>(), C.offs.as<uint32_t>(), C.order.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[3], st));
-  k_accum<BF><<<C.num_cus * 3, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
+  k_accum<BF><<<C.num_cus * 2, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
                                              C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits,
                                              chunk_counter);
   HIP_TRY(hipEventRecord(C.ev[4], st));

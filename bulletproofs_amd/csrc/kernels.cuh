@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* 
 // k % nbins (k_bin_sort's order[]), so lanes of a wave walk lists of near-equal length and the
 // kernel's tail is made of the shortest lists.
 template <int BF>
-__global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
+__global__ void __launch_bounds__(256, 2) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
                                                const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                uint32_t* __restrict__ bsum, uint32_t nbuckets, uint32_t nbins,
                                                int fine_bits, uint32_t* __restrict__ chunk_counter) {
@@ -283,11 +283,30 @@ __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ poin
     uint32_t b = order[gid];
     uint32_t lo = offs[b], hi = offs[b + 1];
     Xyzz acc = E::identity();
+    // software pipeline: the index two entries ahead and the point one entry ahead are in
+    // flight while the current mixed add runs
+    uint32_t ent = lo < hi ? sorted[lo] : 0u;
+    uint32_t ent_n = lo + 1 < hi ? sorted[lo + 1] : 0u;
+    uint4 raw[4];
+    {
+      const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent & 0x7fffffffu));
+      raw[0] = pp[0]; raw[1] = pp[1]; raw[2] = pp[2]; raw[3] = pp[3];
+    }
     for (uint32_t e = lo; e < hi; e++) {
-      uint32_t ent = sorted[e];
-      Aff q = IO::load_dev_affine(points + 16ull * (ent & 0x7fffffffu));
+      uint32_t ent_nn = e + 2 < hi ? sorted[e + 2] : 0u;
+      uint4 nxt[4];
+      {
+        const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent_n & 0x7fffffffu));
+        nxt[0] = pp[0]; nxt[1] = pp[1]; nxt[2] = pp[2]; nxt[3] = pp[3];
+      }
+      uint32_t w[16] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w,
+                        raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
+      Aff q = IO::load_dev_affine(w);
       if (ent >> 31) q = E::neg(q);
       E::madd(acc, q);
+      ent = ent_n;
+      ent_n = ent_nn;
+      raw[0] = nxt[0]; raw[1] = nxt[1]; raw[2] = nxt[2]; raw[3] = nxt[3];
     }
     IO::store_dev_xyzz(bsum + 32ull * b, acc);
   }
