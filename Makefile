@@ -1,5 +1,6 @@
 # Builds the three native artefacts:
 #   bulletproofs_amd/lib/libbpgpu.so   the product: HIP kernels + C ABI (include/bpgpu.h), gfx950
+#   bulletproofs_amd/lib/libarkbp.so   host side above the ABI: C++ mirror of util::msm, Bp, Bp2aryStep, FiatShamirRng
 #   bulletproofs_amd/lib/libbpchk.so   test-only host build of the device arithmetic headers
 #   oracle/_build/libpasta_oracle.so   test-only CPU restatement of the reference algorithms (Oracle B)
 HIPCC ?= hipcc
@@ -8,11 +9,15 @@ CC ?= gcc
 CSRC := bulletproofs_amd/csrc
 LIBDIR := bulletproofs_amd/lib
 
-all: $(LIBDIR)/libbpgpu.so $(LIBDIR)/libbpchk.so oracle/_build/libpasta_oracle.so
+all: $(LIBDIR)/libbpgpu.so $(LIBDIR)/libarkbp.so $(LIBDIR)/libbpchk.so oracle/_build/libpasta_oracle.so
 
 $(LIBDIR)/libbpgpu.so: $(CSRC)/bpgpu.hip $(CSRC)/kernels.cuh $(CSRC)/curve.cuh $(CSRC)/field.cuh $(CSRC)/host_field.h $(CSRC)/pasta_consts.h include/bpgpu.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC $(HIPFLAGS) $< -o $@
+
+# host side above the C ABI (C++ mirror of the reference's Rust interface for this path)
+$(LIBDIR)/libarkbp.so: bulletproofs_amd/host/ark_bp_capi.cpp bulletproofs_amd/host/ark_bp.hpp $(CSRC)/host_field.h $(CSRC)/pasta_consts.h include/bpgpu.h $(LIBDIR)/libbpgpu.so
+	$(CXX) -O2 -std=c++17 -shared -fPIC $< -o $@ -L$(LIBDIR) -lbpgpu -Wl,-rpath,'$$ORIGIN'
 
 $(LIBDIR)/libbpchk.so: $(CSRC)/host_check.cpp $(CSRC)/curve.cuh $(CSRC)/field.cuh $(CSRC)/pasta_consts.h
 	@mkdir -p $(LIBDIR)

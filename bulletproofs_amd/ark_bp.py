@@ -1,0 +1,130 @@
+"""ctypes view of libarkbp.so -- the C++ host side (bulletproofs_amd/host/ark_bp.hpp) that mirrors
+the reference's util::msm / Bp / Bp2aryStep / FiatShamirRng above the bpgpu C ABI.  Plumbing only."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_int, c_size_t, c_void_p
+
+import numpy as np
+
+from . import ffi
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libarkbp.so")
+_lib = None
+
+
+class Panic(RuntimeError):
+    """The reference would have panicked here (assert!/unwrap on this path)."""
+
+
+def load():
+    global _lib
+    if _lib is None:
+        ffi.load()
+        if not os.path.exists(LIB_PATH):
+            raise ffi.BpGpuError(f"{LIB_PATH} is missing: build it with `make`")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.arkbp_last_error.restype = ctypes.c_char_p
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return None if a is None else c_void_p(a.ctypes.data)
+
+
+def _u64(a, w):
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, w)
+
+
+def _check(rc):
+    if rc < 0:
+        raise Panic(load().arkbp_last_error().decode())
+    return rc
+
+
+def msm(curve, bases, scalars):
+    b, s = _u64(bases, 12), _u64(scalars, 4)
+    out = np.zeros(12, np.uint64)
+    _check(load().arkbp_msm(curve, _p(b), c_size_t(len(b)), _p(s), c_size_t(len(s)), _p(out)))
+    return out
+
+
+def ip(curve, a, b):
+    a, b = _u64(a, 4), _u64(b, 4)
+    out = np.zeros(4, np.uint64)
+    _check(load().arkbp_ip(curve, _p(a), c_size_t(len(a)), _p(b), c_size_t(len(b)), _p(out)))
+    return out
+
+
+def commit(curve, a_gens, b_gens, ip_gen, a, b):
+    A, B, q, a, b = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(a, 4), _u64(b, 4)
+    out = np.zeros(12, np.uint64)
+    _check(load().arkbp_commit(curve, _p(A), _p(B), _p(q), _p(a), _p(b), c_size_t(len(a)), _p(out)))
+    return out
+
+
+def bp_prove(curve, a_gens, b_gens, ip_gen, a, b, fs_seed: bytes):
+    """Bp::prove -> dict(ls, rs, challenges, final_a, final_b, prove_ms)"""
+    A, B, q, a, b = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(a, 4), _u64(b, 4)
+    n = len(a)
+    kmax = max(1, (max(n, 1) - 1).bit_length())
+    ls, rs = np.zeros((kmax, 12), np.uint64), np.zeros((kmax, 12), np.uint64)
+    ch = np.zeros((kmax, 4), np.uint64)
+    fa, fb = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    ms = c_double()
+    k = _check(load().arkbp_bp_prove(curve, _p(A), _p(B), _p(q), _p(a), _p(b), c_size_t(n), _p(seed), _p(ls), _p(rs),
+                                     _p(ch), _p(fa), _p(fb), ctypes.byref(ms)))
+    return dict(ls=ls[:k], rs=rs[:k], challenges=ch[:k], final_a=fa, final_b=fb, prove_ms=ms.value)
+
+
+def bp_verify(curve, a_gens, b_gens, ip_gen, result, proof, fs_seed: bytes):
+    """Bp::verify: returns None, raises Panic where the reference's assert_eq! fails."""
+    A, B, q, res = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(result, 12)
+    ls, rs = _u64(proof["ls"], 12), _u64(proof["rs"], 12)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    _check(load().arkbp_bp_verify(curve, _p(A), _p(B), _p(q), _p(res), c_size_t(len(A)), _p(ls), _p(rs), c_size_t(len(ls)),
+                                  _p(_u64(proof["final_a"], 4)), _p(_u64(proof["final_b"], 4)), _p(seed)))
+
+
+def step_prove(curve, a_gens, b_gens, ip_gen, result, a, b, fs_seed: bytes):
+    """Bp2aryStep::prove -> ((l, r), next instance dict, next witness dict)"""
+    A, B, q, res, a, b = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(result, 12), _u64(a, 4), _u64(b, 4)
+    n = len(a)
+    m = max(1, (1 << max(0, (n - 1).bit_length())) // 2)
+    l, r, res2 = np.zeros(12, np.uint64), np.zeros(12, np.uint64), np.zeros(12, np.uint64)
+    A2, B2 = np.zeros((m, 12), np.uint64), np.zeros((m, 12), np.uint64)
+    a2, b2 = np.zeros((m, 4), np.uint64), np.zeros((m, 4), np.uint64)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    k = _check(load().arkbp_2ary_prove(curve, _p(A), _p(B), _p(q), _p(res), _p(a), _p(b), c_size_t(n), _p(seed), _p(l), _p(r),
+                                       _p(A2), _p(B2), _p(a2), _p(b2), _p(res2)))
+    assert k == m
+    return (l, r), dict(a_gens=A2, b_gens=B2, ip_gen=q, result=res2), dict(a=a2, b=b2)
+
+
+def step_verify(curve, a_gens, b_gens, ip_gen, result, l, r, fs_seed: bytes):
+    A, B, q, res = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(result, 12)
+    n = len(A)
+    m = max(1, (1 << max(0, (n - 1).bit_length())) // 2)
+    A2, B2, res2 = np.zeros((m, 12), np.uint64), np.zeros((m, 12), np.uint64), np.zeros(12, np.uint64)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    k = _check(load().arkbp_2ary_verify(curve, _p(A), _p(B), _p(q), _p(res), c_size_t(n), _p(_u64(l, 12)), _p(_u64(r, 12)),
+                                        _p(seed), _p(A2), _p(B2), _p(res2)))
+    assert k == m
+    return dict(a_gens=A2, b_gens=B2, ip_gen=q, result=res2)
+
+
+def fs_challenge(curve, fs_seed: bytes, points_xyz):
+    pts = _u64(points_xyz, 12)
+    out = np.zeros(4, np.uint64)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    _check(load().arkbp_fs_challenge(curve, _p(seed), _p(pts), c_size_t(len(pts)), _p(out)))
+    return out
+
+
+def scalar_inverse(curve, x):
+    out = np.zeros(4, np.uint64)
+    _check(load().arkbp_scalar_inverse(curve, _p(_u64(x, 4)), _p(out)))
+    return out

@@ -1,0 +1,507 @@
+// Host side above the C ABI, in C++ because the reference is compiled Rust and no Rust
+// toolchain exists in the build image: a mirror of the reference's interface for the hot
+// path -- same names, argument meaning and error behaviour (it throws where the reference
+// panics) -- whose bodies dispatch to libbpgpu exactly where the Rust shim would
+// (INTEGRATION.md).  Nothing here computes group arithmetic on the CPU.
+//
+//   util::msm / util::ip / util::zero_pad_to_two_power   src/util/mod.rs:15,17-23,137-144
+//   FiatShamirRng (ark-marlin 0.3, Blake2s + ChaCha20)     src/lib.rs:5
+//   IpaGens / IpaInstance / IpaWitness / IpaRelation       src/relations/ipa.rs:10-160
+//   Bp::{prove, verify}, BpProof                           src/proofs/bp_iter.rs:24-197
+//   Bp2aryStep::{prove, verify}                            src/reductions/bp_2ary_step.rs:19-142
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bpgpu.h"
+#include "../csrc/host_field.h"
+
+namespace ark_bp {
+
+enum Curve : int { Pallas = BPGPU_PALLAS, Vesta = BPGPU_VESTA };
+
+struct Panic : std::runtime_error {  // the reference's only error convention on this path
+  using std::runtime_error::runtime_error;
+};
+inline void check(int rc) {
+  if (rc != 0) throw Panic(std::string("bpgpu: ") + bpgpu_last_error());
+}
+
+// ark-ff Fp256 in memory: 4 x u64, Montgomery form
+struct Fr {
+  uint64_t v[4];
+  bool operator==(const Fr& o) const { return std::memcmp(v, o.v, 32) == 0; }
+};
+// ark-ec GroupProjective in memory: X | Y | Z, each an Fp256; Z = 0 is the identity
+struct G {
+  uint64_t v[12];
+  bool operator==(const G& o) const { return std::memcmp(v, o.v, 96) == 0; }  // both sides normalised
+};
+
+// ---- scalar-field helpers for the few host-side field operations of the protocols ----------
+template <int CURVE>
+struct ScalarOps {
+  using HF = bpgpu::host::HF<1 - CURVE>;
+  using H4 = bpgpu::host::H4;
+  static H4 h(const Fr& a) { H4 r; std::memcpy(r.v, a.v, 32); return r; }
+  static Fr f(const H4& a) { Fr r; std::memcpy(r.v, a.v, 32); return r; }
+  static Fr one() { return f(HF::one()); }
+  static Fr mul(const Fr& a, const Fr& b) { return f(HF::mul(h(a), h(b))); }
+  static Fr square(const Fr& a) { return mul(a, a); }
+  static Fr neg(const Fr& a) { return f(HF::neg(h(a))); }
+  static Fr inverse(const Fr& a) {
+    if (HF::is_zero(h(a))) throw Panic("called `Option::unwrap()` on a `None` value (inverse of zero)");
+    return f(HF::inv(h(a)));
+  }
+};
+
+template <int CURVE>
+struct PointOps {
+  using HF = bpgpu::host::HF<CURVE>;
+  using H4 = bpgpu::host::H4;
+  // xy_inf from the C ABI -> Projective { x, y, z: 1 } or zero() = (0, 1, 0)
+  static G from_xy_inf(const uint64_t out[9]) {
+    G g;
+    H4 one = HF::one();
+    if (out[8]) {
+      std::memset(g.v, 0, 96);
+      std::memcpy(g.v + 4, one.v, 32);
+    } else {
+      std::memcpy(g.v, out, 64);
+      std::memcpy(g.v + 8, one.v, 32);
+    }
+    return g;
+  }
+  // ToBytes for GroupProjective: canonical X | Y | Z (96 bytes)
+  static void to_bytes(const G& g, uint8_t out[96]) {
+    for (int k = 0; k < 3; k++) {
+      H4 t;
+      std::memcpy(t.v, g.v + 4 * k, 32);
+      H4 c = HF::to_canon(t);
+      std::memcpy(out + 32 * k, c.v, 32);
+    }
+  }
+};
+
+// ---- BLAKE2s-256 (RFC 7693), unkeyed ------------------------------------------------------
+class Blake2s {
+ public:
+  static std::array<uint8_t, 32> digest(const uint8_t* data, size_t len) {
+    static const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                   0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+    uint32_t h[8];
+    for (int i = 0; i < 8; i++) h[i] = IV[i];
+    h[0] ^= 0x01010000u ^ 32u;
+    uint64_t t = 0;
+    size_t off = 0;
+    uint8_t block[64];
+    while (len - off > 64) {
+      t += 64;
+      compress(h, data + off, t, false, IV);
+      off += 64;
+    }
+    std::memset(block, 0, 64);
+    if (len > off) std::memcpy(block, data + off, len - off);
+    t += len - off;
+    compress(h, block, t, true, IV);
+    std::array<uint8_t, 32> out;
+    std::memcpy(out.data(), h, 32);
+    return out;
+  }
+
+ private:
+  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  static void compress(uint32_t h[8], const uint8_t* block, uint64_t t, bool last, const uint32_t IV[8]) {
+    static const uint8_t S[10][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+    uint32_t m[16], v[16];
+    std::memcpy(m, block, 64);
+    for (int i = 0; i < 8; i++) {
+      v[i] = h[i];
+      v[8 + i] = IV[i];
+    }
+    v[12] ^= (uint32_t)t;
+    v[13] ^= (uint32_t)(t >> 32);
+    if (last) v[14] = ~v[14];
+    auto mix = [&](int a, int b, int c, int d, uint32_t x, uint32_t y) {
+      v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 16);
+      v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 12);
+      v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 8);
+      v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 7);
+    };
+    for (int r = 0; r < 10; r++) {
+      const uint8_t* s = S[r];
+      mix(0, 4, 8, 12, m[s[0]], m[s[1]]);
+      mix(1, 5, 9, 13, m[s[2]], m[s[3]]);
+      mix(2, 6, 10, 14, m[s[4]], m[s[5]]);
+      mix(3, 7, 11, 15, m[s[6]], m[s[7]]);
+      mix(0, 5, 10, 15, m[s[8]], m[s[9]]);
+      mix(1, 6, 11, 12, m[s[10]], m[s[11]]);
+      mix(2, 7, 8, 13, m[s[12]], m[s[13]]);
+      mix(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+  }
+};
+
+// ---- rand_chacha ChaCha20Rng behind rand_core's BlockRng (64-word buffer) -------------------
+class ChaCha20Rng {
+ public:
+  explicit ChaCha20Rng(const std::array<uint8_t, 32>& seed) {
+    std::memcpy(key_, seed.data(), 32);
+    counter_ = 0;
+    index_ = 64;
+  }
+  uint32_t next_u32() {
+    if (index_ >= 64) {
+      refill();
+      index_ = 0;
+    }
+    return buf_[index_++];
+  }
+  uint64_t next_u64() {
+    uint64_t lo, hi;
+    if (index_ < 63) {
+      lo = buf_[index_];
+      hi = buf_[index_ + 1];
+      index_ += 2;
+    } else if (index_ >= 64) {
+      refill();
+      lo = buf_[0];
+      hi = buf_[1];
+      index_ = 2;
+    } else {
+      lo = buf_[63];
+      refill();
+      hi = buf_[0];
+      index_ = 1;
+    }
+    return lo | (hi << 32);
+  }
+
+ private:
+  static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+  void block(uint64_t ctr, uint32_t* out) const {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 8; i++) s[4 + i] = key_[i];
+    s[12] = (uint32_t)ctr;
+    s[13] = (uint32_t)(ctr >> 32);
+    s[14] = 0;
+    s[15] = 0;
+    uint32_t x[16];
+    std::memcpy(x, s, 64);
+    auto qr = [&](int a, int b, int c, int d) {
+      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+      x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+      x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+    };
+    for (int r = 0; r < 10; r++) {
+      qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+      qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+  }
+  void refill() {
+    for (int i = 0; i < 4; i++) block(counter_ + i, buf_ + 16 * i);
+    counter_ += 4;
+  }
+  uint32_t key_[8];
+  uint64_t counter_;
+  uint32_t buf_[64];
+  int index_;
+};
+
+// ---- ark-marlin 0.3 FiatShamirRng<Blake2s> (src/lib.rs:5) ----------------------------------
+class FiatShamirRng {
+ public:
+  static FiatShamirRng from_seed(const uint8_t* bytes, size_t len) { return FiatShamirRng(Blake2s::digest(bytes, len)); }
+  void absorb(const uint8_t* bytes, size_t len) {
+    std::vector<uint8_t> buf(bytes, bytes + len);
+    buf.insert(buf.end(), seed_.begin(), seed_.end());  // new material first, then the old seed
+    seed_ = Blake2s::digest(buf.data(), buf.size());
+    r_ = ChaCha20Rng(seed_);
+  }
+  template <int CURVE>
+  void absorb(const G& g) {
+    uint8_t b[96];
+    PointOps<CURVE>::to_bytes(g, b);
+    absorb(b, 96);
+  }
+  uint32_t next_u32() { return r_.next_u32(); }
+  uint64_t next_u64() { return r_.next_u64(); }
+  // G::ScalarField::rand(fs): 4 x next_u64, clear the top bit, accept iff < r; limbs are the Montgomery repr
+  template <int CURVE>
+  Fr rand_scalar() {
+    using C = bpgpu::FieldConsts<1 - CURVE>;
+    for (;;) {
+      Fr x;
+      for (int i = 0; i < 4; i++) x.v[i] = next_u64();
+      x.v[3] &= 0x7fffffffffffffffull;
+      for (int i = 3; i >= 0; i--) {
+        if (x.v[i] < C::P64[i]) return x;
+        if (x.v[i] > C::P64[i]) break;
+      }
+    }
+  }
+
+ private:
+  explicit FiatShamirRng(const std::array<uint8_t, 32>& seed) : seed_(seed), r_(seed) {}
+  std::array<uint8_t, 32> seed_;
+  ChaCha20Rng r_;
+};
+
+// ---- util (src/util/mod.rs) -----------------------------------------------------------------
+namespace util {
+// pippenger_msm: zips the two sequences (msm.rs:94-97), so the shorter one decides the length
+template <int CURVE>
+G msm(const G* bases, size_t nb, const Fr* scalars, size_t ns) {
+  size_t n = nb < ns ? nb : ns;
+  uint64_t out[9];
+  check(bpgpu_msm(CURVE, n ? bases->v : nullptr, n ? scalars->v : nullptr, n, out));
+  return PointOps<CURVE>::from_xy_inf(out);
+}
+template <int CURVE>
+G msm(const std::vector<G>& bases, const std::vector<Fr>& scalars) {
+  return msm<CURVE>(bases.data(), bases.size(), scalars.data(), scalars.size());
+}
+template <int CURVE>
+Fr ip(const Fr* a, size_t na, const Fr* b, size_t nb) {
+  if (na != nb) throw Panic("assertion failed: a.len() == b.len()");  // util/mod.rs:18
+  Fr out;
+  check(bpgpu_ip(CURVE, na ? a->v : nullptr, na ? b->v : nullptr, na, out.v));
+  return out;
+}
+inline size_t next_power_of_two(size_t n) {
+  size_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+template <class Z>
+std::vector<Z> zero_pad_to_two_power(const std::vector<Z>& v, const Z& zero) {  // util/mod.rs:137-144
+  std::vector<Z> out(v);
+  out.resize(next_power_of_two(v.size()), zero);
+  return out;
+}
+}  // namespace util
+
+// ---- relations (src/relations/ipa.rs) ---------------------------------------------------------
+struct IpaGens {
+  size_t vec_size = 0;
+  std::vector<G> a_gens, b_gens;
+  G ip_gen{};
+};
+struct IpaInstance {
+  IpaGens gens;
+  G result{};
+};
+struct IpaWitness {
+  std::vector<Fr> a, b;
+};
+
+template <int CURVE>
+G zero_point() {
+  uint64_t o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
+  return PointOps<CURVE>::from_xy_inf(o);
+}
+
+template <int CURVE>
+struct IpaRelation {
+  // commit_for_witness (ipa.rs:37-41) as one MSM over a_gens | b_gens | ip_gen
+  static G commit_for_witness(const IpaGens& g, const IpaWitness& w) {
+    std::vector<G> pts(g.a_gens);
+    pts.insert(pts.end(), g.b_gens.begin(), g.b_gens.end());
+    pts.push_back(g.ip_gen);
+    std::vector<Fr> sc(w.a);
+    sc.insert(sc.end(), w.b.begin(), w.b.end());
+    sc.push_back(util::ip<CURVE>(w.a.data(), w.a.size(), w.b.data(), w.b.size()));
+    return util::msm<CURVE>(pts, sc);
+  }
+  // check (ipa.rs:134-146)
+  static void check(const IpaInstance& x, const IpaWitness& w) {
+    if (x.gens.a_gens.size() != x.gens.vec_size || x.gens.b_gens.size() != x.gens.vec_size ||
+        w.a.size() != x.gens.vec_size || w.b.size() != x.gens.vec_size)
+      throw Panic("assertion failed: vector sizes");
+    if (!(commit_for_witness(x.gens, w) == x.result)) throw Panic("assertion failed: commitment");
+  }
+};
+
+// ---- proofs::bp_iter (src/proofs/bp_iter.rs) --------------------------------------------------
+struct BpProof {
+  std::vector<G> ls, rs;
+  Fr final_a{}, final_b{};
+};
+
+template <int CURVE>
+struct Bp {
+  using S = ScalarOps<CURVE>;
+  using P = PointOps<CURVE>;
+
+  // bp_iter.rs:49-128.  The vectors go to HBM once; per round only L, R come back and
+  // x, x^-1 go down.  Optionally reports the challenges (not part of the reference's proof).
+  static BpProof prove(const IpaInstance& instance, const IpaWitness& witness, FiatShamirRng& fs,
+                       std::vector<Fr>* challenges_out = nullptr) {
+    const size_t n = witness.a.size();
+    if (witness.b.size() != n || instance.gens.a_gens.size() != n || instance.gens.b_gens.size() != n)
+      throw Panic("assertion failed: vector sizes");
+    bpgpu_ipa* sess = nullptr;
+    check(bpgpu_ipa_begin(CURVE, n ? instance.gens.a_gens.data()->v : nullptr, n ? instance.gens.b_gens.data()->v : nullptr,
+                          instance.gens.ip_gen.v, n ? witness.a.data()->v : nullptr, n ? witness.b.data()->v : nullptr, n,
+                          &sess));
+    BpProof proof;
+    try {
+      while (bpgpu_ipa_len(sess) > 1) {
+        uint64_t lo[9], ro[9];
+        check(bpgpu_ipa_round_lr(sess, lo, ro));
+        G l = P::from_xy_inf(lo), r = P::from_xy_inf(ro);
+        proof.ls.push_back(l);
+        proof.rs.push_back(r);
+        fs.absorb<CURVE>(l);
+        fs.absorb<CURVE>(r);
+        Fr x = fs.rand_scalar<CURVE>();
+        Fr x_inv = S::inverse(x);
+        if (challenges_out) challenges_out->push_back(x);
+        check(bpgpu_ipa_round_fold(sess, x.v, x_inv.v));
+      }
+      check(bpgpu_ipa_finish(sess, proof.final_a.v, proof.final_b.v));
+    } catch (...) {
+      bpgpu_ipa_free(sess);
+      throw;
+    }
+    bpgpu_ipa_free(sess);
+    return proof;
+  }
+
+  // bp_iter.rs:25-42 (iterative form of the same recursion)
+  static std::vector<Fr> scalars_from_challenges(const std::vector<Fr>& challs) {
+    std::vector<Fr> left{S::one()};
+    for (size_t k = challs.size(); k-- > 0;) {
+      Fr ch = challs[k], ch_inv = S::inverse(ch);
+      size_t n = left.size();
+      left.resize(2 * n);
+      for (size_t i = 0; i < n; i++) {
+        left[n + i] = S::mul(left[i], ch);
+        left[i] = S::mul(left[i], ch_inv);
+      }
+    }
+    return left;
+  }
+
+  // bp_iter.rs:130-178: panics (throws) unless the single big MSM reproduces the commitment
+  static void verify(const IpaInstance& instance, const BpProof& proof, FiatShamirRng& fs) {
+    std::vector<G> a_gen = util::zero_pad_to_two_power(instance.gens.a_gens, zero_point<CURVE>());
+    std::vector<G> b_gen = util::zero_pad_to_two_power(instance.gens.b_gens, zero_point<CURVE>());
+    std::vector<Fr> challenges, challenges_inv;
+    for (size_t i = 0; i < proof.ls.size(); i++) {
+      fs.absorb<CURVE>(proof.ls[i]);
+      fs.absorb<CURVE>(proof.rs[i]);
+      challenges.push_back(fs.rand_scalar<CURVE>());
+    }
+    for (const Fr& c : challenges) challenges_inv.push_back(S::inverse(c));
+    std::vector<Fr> scalars = scalars_from_challenges(challenges);
+    std::vector<Fr> scalars_inv = scalars_from_challenges(challenges_inv);
+    if (scalars.size() != a_gen.size()) throw Panic("assertion failed: proof length does not match the generators");
+    std::vector<G> pts;
+    std::vector<Fr> sc;
+    pts.reserve(2 * a_gen.size() + 1 + 2 * proof.ls.size());
+    sc.reserve(pts.capacity());
+    pts.insert(pts.end(), a_gen.begin(), a_gen.end());
+    for (const Fr& s : scalars) sc.push_back(S::mul(s, proof.final_a));
+    pts.insert(pts.end(), b_gen.begin(), b_gen.end());
+    for (const Fr& s : scalars_inv) sc.push_back(S::mul(s, proof.final_b));
+    pts.push_back(instance.gens.ip_gen);
+    sc.push_back(S::mul(proof.final_a, proof.final_b));
+    for (size_t j = 0; j < proof.ls.size(); j++) {
+      pts.push_back(proof.ls[j]);
+      sc.push_back(S::neg(S::square(challenges[j])));
+      pts.push_back(proof.rs[j]);
+      sc.push_back(S::neg(S::square(challenges_inv[j])));
+    }
+    if (!(instance.result == util::msm<CURVE>(pts, sc))) throw Panic("assertion failed: `(left == right)` in Bp::verify");
+  }
+  static size_t proof_size(const BpProof& p) { return 2 * (1 + p.ls.size()); }  // bp_iter.rs:187-189
+};
+
+// ---- reductions::bp_2ary_step (src/reductions/bp_2ary_step.rs) --------------------------------
+template <int CURVE>
+struct Bp2aryStep {
+  using S = ScalarOps<CURVE>;
+  using P = PointOps<CURVE>;
+  struct Proof {
+    G l, r;
+  };
+  struct ProveOut {
+    Proof proof;
+    IpaInstance instance;
+    IpaWitness witness;
+  };
+  static G p_next(const G& l, const G& r, const G& p, const Fr& x, const Fr& x_inv) {  // :59,105
+    G pts[3] = {l, r, p};
+    Fr sc[3] = {S::square(x), S::square(x_inv), S::one()};
+    return util::msm<CURVE>(pts, 3, sc, 3);
+  }
+  // :24-87
+  static ProveOut prove(const IpaInstance& instance, const IpaWitness& witness, FiatShamirRng& fs) {
+    const size_t n0 = witness.a.size();
+    if (util::next_power_of_two(n0) % 2 != 0) throw Panic("assertion failed: a.len() % 2 == 0");
+    bpgpu_ipa* sess = nullptr;
+    check(bpgpu_ipa_begin(CURVE, n0 ? instance.gens.a_gens.data()->v : nullptr, n0 ? instance.gens.b_gens.data()->v : nullptr,
+                          instance.gens.ip_gen.v, n0 ? witness.a.data()->v : nullptr, n0 ? witness.b.data()->v : nullptr, n0,
+                          &sess));
+    ProveOut out;
+    try {
+      uint64_t lo[9], ro[9];
+      check(bpgpu_ipa_round_lr(sess, lo, ro));
+      out.proof.l = P::from_xy_inf(lo);
+      out.proof.r = P::from_xy_inf(ro);
+      fs.absorb<CURVE>(out.proof.l);
+      fs.absorb<CURVE>(out.proof.r);
+      Fr x = fs.rand_scalar<CURVE>(), x_inv = S::inverse(x);
+      check(bpgpu_ipa_round_fold(sess, x.v, x_inv.v));
+      const size_t n = bpgpu_ipa_len(sess);
+      out.instance.gens.vec_size = n;
+      out.instance.gens.ip_gen = instance.gens.ip_gen;
+      out.instance.gens.a_gens.resize(n);
+      out.instance.gens.b_gens.resize(n);
+      out.witness.a.resize(n);
+      out.witness.b.resize(n);
+      check(bpgpu_ipa_export(sess, out.instance.gens.a_gens.data()->v, out.instance.gens.b_gens.data()->v,
+                             out.witness.a.data()->v, out.witness.b.data()->v));
+      out.instance.result = p_next(out.proof.l, out.proof.r, instance.result, x, x_inv);
+    } catch (...) {
+      bpgpu_ipa_free(sess);
+      throw;
+    }
+    bpgpu_ipa_free(sess);
+    return out;
+  }
+  // :88-125
+  static IpaInstance verify(const IpaInstance& instance, const Proof& proof, FiatShamirRng& fs) {
+    std::vector<G> a_gen = util::zero_pad_to_two_power(instance.gens.a_gens, zero_point<CURVE>());
+    std::vector<G> b_gen = util::zero_pad_to_two_power(instance.gens.b_gens, zero_point<CURVE>());
+    if (a_gen.size() % 2 != 0) throw Panic("assertion failed: a_gen.len() % 2 == 0");
+    const size_t n = a_gen.size() / 2;
+    fs.absorb<CURVE>(proof.l);
+    fs.absorb<CURVE>(proof.r);
+    Fr x = fs.rand_scalar<CURVE>(), x_inv = S::inverse(x);
+    IpaInstance next;
+    next.gens.vec_size = n;
+    next.gens.ip_gen = instance.gens.ip_gen;
+    next.gens.a_gens.resize(n);
+    next.gens.b_gens.resize(n);
+    check(bpgpu_fold_points(CURVE, a_gen.data()->v, n, x_inv.v, x.v, next.gens.a_gens.data()->v));
+    check(bpgpu_fold_points(CURVE, b_gen.data()->v, n, x.v, x_inv.v, next.gens.b_gens.data()->v));
+    next.result = p_next(proof.l, proof.r, instance.result, x, x_inv);
+    return next;
+  }
+};
+
+}  // namespace ark_bp

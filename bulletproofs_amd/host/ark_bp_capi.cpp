@@ -1,0 +1,214 @@
+// C entry points over ark_bp.hpp for the Python tests and bench.py (ctypes).  A Rust build of
+// the reference would not use this file: it calls include/bpgpu.h directly.
+#include <chrono>
+#include <cstring>
+#include <string>
+
+#include "ark_bp.hpp"
+
+using namespace ark_bp;
+
+namespace {
+thread_local std::string g_msg;
+
+IpaInstance make_instance(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result,
+                          size_t n) {
+  IpaInstance x;
+  x.gens.vec_size = n;
+  x.gens.a_gens.resize(n);
+  x.gens.b_gens.resize(n);
+  if (n) {
+    std::memcpy(x.gens.a_gens.data(), a_gens, n * 96);
+    std::memcpy(x.gens.b_gens.data(), b_gens, n * 96);
+  }
+  std::memcpy(x.gens.ip_gen.v, ip_gen, 96);
+  if (result) std::memcpy(x.result.v, result, 96);
+  return x;
+}
+IpaWitness make_witness(const uint64_t* a, const uint64_t* b, size_t n) {
+  IpaWitness w;
+  w.a.resize(n);
+  w.b.resize(n);
+  if (n) {
+    std::memcpy(w.a.data(), a, n * 32);
+    std::memcpy(w.b.data(), b, n * 32);
+  }
+  return w;
+}
+
+template <class F>
+int guarded(F f) {
+  try {
+    return f();
+  } catch (const Panic& p) {
+    g_msg = p.what();
+    return -100;
+  } catch (const std::exception& e) {
+    g_msg = e.what();
+    return -101;
+  }
+}
+
+template <int CURVE>
+int bp_prove(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* a, const uint64_t* b,
+             size_t n, const uint8_t* fs_seed, uint64_t* ls, uint64_t* rs, uint64_t* challenges, uint64_t* final_a,
+             uint64_t* final_b, double* prove_ms) {
+  IpaInstance x = make_instance(a_gens, b_gens, ip_gen, nullptr, n);
+  IpaWitness w = make_witness(a, b, n);
+  FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
+  std::vector<Fr> ch;
+  auto t0 = std::chrono::steady_clock::now();
+  BpProof pf = Bp<CURVE>::prove(x, w, fs, &ch);  // the window test_ipa times (src/lib.rs:119-121)
+  auto t1 = std::chrono::steady_clock::now();
+  if (prove_ms) *prove_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  for (size_t i = 0; i < pf.ls.size(); i++) {
+    std::memcpy(ls + 12 * i, pf.ls[i].v, 96);
+    std::memcpy(rs + 12 * i, pf.rs[i].v, 96);
+    if (challenges) std::memcpy(challenges + 4 * i, ch[i].v, 32);
+  }
+  std::memcpy(final_a, pf.final_a.v, 32);
+  std::memcpy(final_b, pf.final_b.v, 32);
+  return (int)pf.ls.size();
+}
+
+template <int CURVE>
+int bp_verify(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result, size_t n,
+              const uint64_t* ls, const uint64_t* rs, size_t k, const uint64_t* final_a, const uint64_t* final_b,
+              const uint8_t* fs_seed) {
+  IpaInstance x = make_instance(a_gens, b_gens, ip_gen, result, n);
+  BpProof pf;
+  pf.ls.resize(k);
+  pf.rs.resize(k);
+  if (k) {
+    std::memcpy(pf.ls.data(), ls, k * 96);
+    std::memcpy(pf.rs.data(), rs, k * 96);
+  }
+  std::memcpy(pf.final_a.v, final_a, 32);
+  std::memcpy(pf.final_b.v, final_b, 32);
+  FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
+  Bp<CURVE>::verify(x, pf, fs);
+  return 0;
+}
+
+template <int CURVE>
+int step_prove(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result,
+               const uint64_t* a, const uint64_t* b, size_t n, const uint8_t* fs_seed, uint64_t* l, uint64_t* r,
+               uint64_t* a_gens_next, uint64_t* b_gens_next, uint64_t* a_next, uint64_t* b_next, uint64_t* result_next) {
+  IpaInstance x = make_instance(a_gens, b_gens, ip_gen, result, n);
+  IpaWitness w = make_witness(a, b, n);
+  FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
+  auto o = Bp2aryStep<CURVE>::prove(x, w, fs);
+  size_t m = o.witness.a.size();
+  std::memcpy(l, o.proof.l.v, 96);
+  std::memcpy(r, o.proof.r.v, 96);
+  std::memcpy(a_gens_next, o.instance.gens.a_gens.data(), m * 96);
+  std::memcpy(b_gens_next, o.instance.gens.b_gens.data(), m * 96);
+  std::memcpy(a_next, o.witness.a.data(), m * 32);
+  std::memcpy(b_next, o.witness.b.data(), m * 32);
+  std::memcpy(result_next, o.instance.result.v, 96);
+  return (int)m;
+}
+
+template <int CURVE>
+int step_verify(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result, size_t n,
+                const uint64_t* l, const uint64_t* r, const uint8_t* fs_seed, uint64_t* a_gens_next, uint64_t* b_gens_next,
+                uint64_t* result_next) {
+  IpaInstance x = make_instance(a_gens, b_gens, ip_gen, result, n);
+  typename Bp2aryStep<CURVE>::Proof pf;
+  std::memcpy(pf.l.v, l, 96);
+  std::memcpy(pf.r.v, r, 96);
+  FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
+  IpaInstance nx = Bp2aryStep<CURVE>::verify(x, pf, fs);
+  size_t m = nx.gens.a_gens.size();
+  std::memcpy(a_gens_next, nx.gens.a_gens.data(), m * 96);
+  std::memcpy(b_gens_next, nx.gens.b_gens.data(), m * 96);
+  std::memcpy(result_next, nx.result.v, 96);
+  return (int)m;
+}
+}  // namespace
+
+#define BY_CURVE(fn, ...) (curve == 0 ? fn<0>(__VA_ARGS__) : fn<1>(__VA_ARGS__))
+
+extern "C" {
+const char* arkbp_last_error(void) { return g_msg.c_str(); }
+
+// util::msm with the reference's zip semantics (the shorter sequence decides); out: 12 x u64
+int arkbp_msm(int curve, const uint64_t* bases, size_t nb, const uint64_t* scalars, size_t ns, uint64_t* out) {
+  return guarded([&] {
+    G g = curve == 0 ? util::msm<0>((const G*)bases, nb, (const Fr*)scalars, ns)
+                     : util::msm<1>((const G*)bases, nb, (const Fr*)scalars, ns);
+    std::memcpy(out, g.v, 96);
+    return 0;
+  });
+}
+int arkbp_ip(int curve, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) {
+  return guarded([&] {
+    Fr r = curve == 0 ? util::ip<0>((const Fr*)a, na, (const Fr*)b, nb) : util::ip<1>((const Fr*)a, na, (const Fr*)b, nb);
+    std::memcpy(out, r.v, 32);
+    return 0;
+  });
+}
+int arkbp_commit(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* a,
+                 const uint64_t* b, size_t n, uint64_t* result) {
+  return guarded([&] {
+    IpaInstance x = make_instance(a_gens, b_gens, ip_gen, nullptr, n);
+    IpaWitness w = make_witness(a, b, n);
+    G g = curve == 0 ? IpaRelation<0>::commit_for_witness(x.gens, w) : IpaRelation<1>::commit_for_witness(x.gens, w);
+    std::memcpy(result, g.v, 96);
+    return 0;
+  });
+}
+// returns the number of rounds (log2 of the padded length) or a negative code
+int arkbp_bp_prove(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* a,
+                   const uint64_t* b, size_t n, const uint8_t* fs_seed, uint64_t* ls, uint64_t* rs, uint64_t* challenges,
+                   uint64_t* final_a, uint64_t* final_b, double* prove_ms) {
+  return guarded([&] {
+    return BY_CURVE(bp_prove, a_gens, b_gens, ip_gen, a, b, n, fs_seed, ls, rs, challenges, final_a, final_b, prove_ms);
+  });
+}
+// 0 = accepted; -100 = the reference's verify would have panicked
+int arkbp_bp_verify(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen,
+                    const uint64_t* result, size_t n, const uint64_t* ls, const uint64_t* rs, size_t k,
+                    const uint64_t* final_a, const uint64_t* final_b, const uint8_t* fs_seed) {
+  return guarded([&] { return BY_CURVE(bp_verify, a_gens, b_gens, ip_gen, result, n, ls, rs, k, final_a, final_b, fs_seed); });
+}
+int arkbp_2ary_prove(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen,
+                     const uint64_t* result, const uint64_t* a, const uint64_t* b, size_t n, const uint8_t* fs_seed,
+                     uint64_t* l, uint64_t* r, uint64_t* a_gens_next, uint64_t* b_gens_next, uint64_t* a_next,
+                     uint64_t* b_next, uint64_t* result_next) {
+  return guarded([&] {
+    return BY_CURVE(step_prove, a_gens, b_gens, ip_gen, result, a, b, n, fs_seed, l, r, a_gens_next, b_gens_next, a_next,
+                    b_next, result_next);
+  });
+}
+int arkbp_2ary_verify(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen,
+                      const uint64_t* result, size_t n, const uint64_t* l, const uint64_t* r, const uint8_t* fs_seed,
+                      uint64_t* a_gens_next, uint64_t* b_gens_next, uint64_t* result_next) {
+  return guarded([&] {
+    return BY_CURVE(step_verify, a_gens, b_gens, ip_gen, result, n, l, r, fs_seed, a_gens_next, b_gens_next, result_next);
+  });
+}
+// Fiat-Shamir primitive checks for the CPU tests (no GPU needed)
+int arkbp_fs_challenge(int curve, const uint8_t* fs_seed, const uint64_t* points_xyz, size_t npoints, uint64_t* out) {
+  return guarded([&] {
+    FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
+    for (size_t i = 0; i < npoints; i++) {
+      G g;
+      std::memcpy(g.v, points_xyz + 12 * i, 96);
+      if (curve == 0) fs.absorb<0>(g); else fs.absorb<1>(g);
+    }
+    Fr x = curve == 0 ? fs.rand_scalar<0>() : fs.rand_scalar<1>();
+    std::memcpy(out, x.v, 32);
+    return 0;
+  });
+}
+int arkbp_scalar_inverse(int curve, const uint64_t* x, uint64_t* out) {
+  return guarded([&] {
+    Fr a;
+    std::memcpy(a.v, x, 32);
+    Fr r = curve == 0 ? ScalarOps<0>::inverse(a) : ScalarOps<1>::inverse(a);
+    std::memcpy(out, r.v, 32);
+    return 0;
+  });
+}
+}
