@@ -76,7 +76,7 @@ struct Ctx {
   int num_cus = 256;
   float msm_ms[8] = {};
   // MSM workspace (grow-only)
-  DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum;
+  DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy;
   // staging for host-buffer entry points
   DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
   std::vector<uint32_t> h_winsum;
@@ -188,6 +188,18 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   uint32_t* bin_count = C.counts.as<uint32_t>();
   uint32_t* chunk_counter = bin_count + (size_t)sp.nbins * BIN_PAD;  // zeroed with bin_count
   uint32_t* bin_cursor = chunk_counter + 16;
+  // heavy-bucket lists: at most entries/HEAVY_T heavy buckets and entries/HEAVY_PIECE + that many pieces
+  const uint64_t entries = slots * W;
+  const size_t max_heavy = (size_t)(entries / HEAVY_T) + 1, max_pieces = (size_t)(entries / HEAVY_PIECE) + max_heavy;
+  TRY(C.heavy.ensure((3 * max_heavy + 2 * max_pieces + 32 * max_pieces) * 4));
+  HeavyLists hv;
+  hv.counters = chunk_counter + 4;
+  hv.bucket = C.heavy.as<uint32_t>();
+  hv.piece0 = hv.bucket + max_heavy;
+  hv.npieces = hv.piece0 + max_heavy;
+  hv.piece_lo = hv.npieces + max_heavy;
+  hv.piece_hi = hv.piece_lo + max_pieces;
+  hv.psum = hv.piece_hi + max_pieces;
   uint32_t* bin_start = C.cursor.as<uint32_t>();
 
   hipStream_t st = C.stream;
@@ -200,11 +212,13 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
                                                      C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>());
   HIP_TRY(hipEventRecord(C.ev[2], st));
   k_bin_sort<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
-                                        C.sorted.as<uint32_t>(), C.offs.as<uint32_t>(), C.order.as<uint32_t>());
+                                        C.sorted.as<uint32_t>(), C.offs.as<uint32_t>(), C.order.as<uint32_t>(), hv);
   HIP_TRY(hipEventRecord(C.ev[3], st));
   k_accum<BF><<<C.num_cus * 2, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
                                              C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits,
                                              chunk_counter);
+  k_accum_heavy<BF><<<C.num_cus * 2, 256, 0, st>>>(d_points, C.sorted.as<uint32_t>(), hv);
+  k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[4], st));
   k_reduce1<BF><<<cdiv(nruns, 64), 64, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s, c - 1);
   k_reduce2<BF><<<plan.M * W, 256, 0, st>>>(C.partial.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window);
@@ -425,7 +439,7 @@ void bpgpu_shutdown(void) {
   if (!g_ctx.ready) return;
   (void)hipSetDevice(g_ctx.device);
   (void)hipStreamSynchronize(g_ctx.stream);
-  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial,
+  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial, &g_ctx.heavy,
                     &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip})
     b->release();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);

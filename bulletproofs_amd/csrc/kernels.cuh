@@ -50,6 +50,17 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t (&w)[8], int pos
 //   k_part_scatter  digits again -> (index|sign, fine) entries appended to their bin
 //   k_bin_sort      one workgroup per bin: LDS counting sort by fine bucket -> sorted[], offs[]
 // ---------------------------------------------------------------------------
+constexpr uint32_t HEAVY_T = 128;       // longest list a single lane walks
+constexpr uint32_t HEAVY_PIECE = 2048;  // entries per wave-piece of a heavy bucket
+struct HeavyLists {
+  uint32_t* counters;  // [0] heavy buckets, [1] pieces, [2] piece work counter (all zeroed per MSM)
+  uint32_t* bucket;    // per heavy bucket: bucket id
+  uint32_t* piece0;    //                   first piece
+  uint32_t* npieces;   //                   number of pieces
+  uint32_t* piece_lo;  // per piece: [lo, hi) in sorted[]
+  uint32_t* piece_hi;
+  uint32_t* psum;      // per piece: XYZZ partial sum (32 words)
+};
 struct SortPlan {
   int fine_bits;       // buckets per bin = 2^fine_bits (<= 1024)
   uint32_t nbins;      // M * W << (c - 1 - fine_bits)
@@ -194,7 +205,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
 __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* __restrict__ bin_start,
                                                    const uint32_t* __restrict__ ent_idx,
                                                    const uint16_t* __restrict__ ent_fine, uint32_t* __restrict__ sorted,
-                                                   uint32_t* __restrict__ offs, uint32_t* __restrict__ order) {
+                                                   uint32_t* __restrict__ offs, uint32_t* __restrict__ order, HeavyLists hv) {
   __shared__ uint32_t cnt[1024];
   __shared__ uint32_t part[1024];
   const uint32_t bin = blockIdx.x, tid = threadIdx.x;
@@ -217,6 +228,22 @@ __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* 
   if (tid < F) offs[(uint64_t)bin * F + tid] = start;
   if (bin == gridDim.x - 1 && tid == 0) offs[(uint64_t)gridDim.x * F] = be;
   cnt[tid] = start;  // becomes the write cursor
+  // a bucket with more than HEAVY_T entries is cut into pieces of HEAVY_PIECE entries that whole
+  // waves accumulate (k_accum_heavy / k_heavy_merge); k_accum skips it
+  if (tid < F && mine > HEAVY_T) {
+    uint32_t np = (mine + HEAVY_PIECE - 1) / HEAVY_PIECE;
+    uint32_t h = atomicAdd(&hv.counters[0], 1u);
+    uint32_t p0 = atomicAdd(&hv.counters[1], np);
+    hv.bucket[h] = bin * F + tid;
+    hv.piece0[h] = p0;
+    hv.npieces[h] = np;
+    for (uint32_t i = 0; i < np; i++) {
+      uint32_t lo = start + i * HEAVY_PIECE;
+      uint32_t hi = lo + HEAVY_PIECE < start + mine ? lo + HEAVY_PIECE : start + mine;
+      hv.piece_lo[p0 + i] = lo;
+      hv.piece_hi[p0 + i] = hi;
+    }
+  }
   __syncthreads();
   // order[]: this bin's buckets by decreasing size, so that the 64 lanes of a k_accum wave
   // walk lists of (nearly) equal length
@@ -267,7 +294,7 @@ __global__ void __launch_bounds__(256, 2) k_accum(const uint32_t* __restrict__ p
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t nchunks = (nbuckets + 63u) >> 6;
   const uint32_t F = 1u << fine_bits;
-  for (;;) {
+  for (uint32_t it = 0; it <= nchunks; it++) {  // bounded: a wave can never pull more than every chunk
     uint32_t k = 0;
     if (lane == 0) k = atomicAdd(chunk_counter, 1u);
     k = __builtin_amdgcn_readfirstlane(k);
@@ -279,9 +306,16 @@ __global__ void __launch_bounds__(256, 2) k_accum(const uint32_t* __restrict__ p
     } else {
       gid = k * 64u + lane;
     }
-    if (gid >= nbuckets) continue;
-    uint32_t b = order[gid];
-    uint32_t lo = offs[b], hi = offs[b + 1];
+    // no lane may leave the loop body early: the chunk counter is read by lane 0 for the whole wave
+    bool act = gid < nbuckets;
+    uint32_t b = 0, lo = 0, hi = 0;
+    if (act) {
+      b = order[gid];
+      lo = offs[b];
+      hi = offs[b + 1];
+      act = hi - lo <= HEAVY_T;  // k_accum_heavy owns longer lists
+    }
+    if (!act) hi = lo;
     Xyzz acc = E::identity();
     // software pipeline: the index two entries ahead and the point one entry ahead are in
     // flight while the current mixed add runs
@@ -308,7 +342,72 @@ __global__ void __launch_bounds__(256, 2) k_accum(const uint32_t* __restrict__ p
       ent_n = ent_nn;
       raw[0] = nxt[0]; raw[1] = nxt[1]; raw[2] = nxt[2]; raw[3] = nxt[3];
     }
-    IO::store_dev_xyzz(bsum + 32ull * b, acc);
+    if (act) IO::store_dev_xyzz(bsum + 32ull * b, acc);
+  }
+}
+
+// sum over the 64 lanes of a wave, result valid in lane 0
+template <int BF>
+__device__ __forceinline__ Xyzz wave_sum_xyzz(Xyzz acc) {
+  using E = Ec<BF>;
+#pragma unroll 1
+  for (int off = 32; off >= 1; off >>= 1) {
+    Xyzz o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      o.x.l[i] = __shfl_down(acc.x.l[i], off, 64);
+      o.y.l[i] = __shfl_down(acc.y.l[i], off, 64);
+      o.zz.l[i] = __shfl_down(acc.zz.l[i], off, 64);
+      o.zzz.l[i] = __shfl_down(acc.zzz.l[i], off, 64);
+    }
+    o.inf = __shfl_down((int)acc.inf, off, 64) != 0;
+    acc = E::add(acc, o);
+  }
+  return acc;
+}
+
+// Heavy buckets (skewed scalars; also the top window, whose few significant bits leave it a
+// handful of buckets): persistent waves pull pieces of <= HEAVY_PIECE entries; the 64 lanes
+// stride through the piece and their partial sums are combined across the wave.
+template <int BF>
+__global__ void __launch_bounds__(256, 2) k_accum_heavy(const uint32_t* __restrict__ points,
+                                                        const uint32_t* __restrict__ sorted, HeavyLists hv) {
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t npieces = hv.counters[1];
+  for (uint32_t it = 0; it <= npieces; it++) {
+    uint32_t p = 0;
+    if (lane == 0) p = atomicAdd(&hv.counters[2], 1u);
+    p = __builtin_amdgcn_readfirstlane(p);
+    if (p >= npieces) break;
+    const uint32_t lo = hv.piece_lo[p], hi = hv.piece_hi[p];
+    Xyzz acc = E::identity();
+    for (uint32_t e = lo + lane; e < hi; e += 64) {
+      uint32_t ent = sorted[e];
+      Aff q = IO::load_dev_affine(points + 16ull * (ent & 0x7fffffffu));
+      if (ent >> 31) q = E::neg(q);
+      E::madd(acc, q);
+    }
+    acc = wave_sum_xyzz<BF>(acc);
+    if (lane == 0) IO::store_dev_xyzz(hv.psum + 32ull * p, acc);
+  }
+}
+
+// bsum[heavy bucket] = sum of its pieces; one wave per heavy bucket (grid-stride)
+template <int BF>
+__global__ void __launch_bounds__(256, 2) k_heavy_merge(HeavyLists hv, uint32_t* __restrict__ bsum) {
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nheavy = hv.counters[0];
+  for (uint32_t h = wave; h < nheavy; h += nwaves) {
+    const uint32_t p0 = hv.piece0[h], np = hv.npieces[h];
+    Xyzz acc = E::identity();
+    for (uint32_t i = lane; i < np; i += 64) acc = E::add(acc, IO::load_dev_xyzz(hv.psum + 32ull * (p0 + i)));
+    acc = wave_sum_xyzz<BF>(acc);
+    if (lane == 0) IO::store_dev_xyzz(bsum + 32ull * hv.bucket[h], acc);
   }
 }
 

@@ -138,3 +138,34 @@ def test_bp_prove_session(ffi, c, n):
     assert H.scalars_from_abi(c, fa)[0] == want.final_a and H.scalars_from_abi(c, fb)[0] == want.final_b
     # the proof verifies (reference: bp_iter.rs:130-178)
     assert pm.bp_verify(c, inst, want, pm.FiatShamirRng(fs_seed))
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_msm_skewed_scalars(ffi, c):
+    """Skewed digit distributions (heavy buckets): repeated scalars, tiny scalars, all ones, scalars that
+    differ only in their low bits, and window widths whose top window holds only a few values."""
+    from oracle import c_oracle as co
+    cid = c.curve_id
+    n = 6000
+    pts = co.gen_points(cid, 77, n, threads=4)
+    pts[17] = pts[16]
+    rs = np.random.default_rng(5)
+    base = H.rand_scalars(c, 4, 31)
+    cases = {
+        "same": [base[0]] * n,
+        "four values": [base[i % 4] for i in range(n)],
+        "tiny": [int(v) for v in rs.integers(0, 1 << 16, n)],
+        "ones": [1] * n,
+        "minus ones": [c.r - 1] * n,
+        "low bits differ": [(base[1] & ~0xFFFF) | int(v) for v in rs.integers(0, 1 << 16, n)],
+        "zeros and one": [0] * (n - 1) + [base[2]],
+    }
+    for name, xs in cases.items():
+        sc = H.scalars_abi(c, xs)
+        want = co.msm_pippenger(cid, pts, sc, threads=4)
+        for bits in (0, 12, 14):
+            ffi.set_window_bits(bits)
+            got = ffi.msm(cid, pts, sc)
+            ok = (int(got[8]) == 0 and (got[:8] == want[:8]).all()) or (int(got[8]) == 1 and not want[8:].any())
+            assert ok, (name, bits)
+    ffi.set_window_bits(0)
