@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="override the MSM window width (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=20, help="log2 of the CPU-baseline sample size")
+    ap.add_argument("--ipa-log2n", type=int, default=20, help="log2 N of the secondary IPA-prove measurement (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -175,12 +176,35 @@ def main():
             "host_to_host": {"ms": h2h * 1e3, "points_per_s": n / h2h,
                              "note": "host buffers in, PCIe + Jacobian->affine conversion included (msm_bench.rs:45-48 window)"},
         }
+        if world == 1 and args.ipa_log2n:
+            out["ipa_prove"] = ipa_prove_leg(ffi, curve, args.ipa_log2n)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ffi, curve, pts, sc, min(args.cpu_log2n, args.log2n))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ipa_prove_leg(ffi, curve, log2n):
+    """Secondary metric of BASELINE.json: classic Bulletproofs IPA prove (Bp::prove, reference
+    src/proofs/bp_iter.rs:49-128) at N = 2^log2n through the C++ host side; the timed window is the
+    reference's own (around i.prove, src/lib.rs:119-121): host vectors in, proof out, Fiat-Shamir
+    on the host between rounds."""
+    from bulletproofs_amd import ark_bp
+    n = 1 << log2n
+    pts = synth_points(ffi, curve, 2 * n + 1, seed=77)
+    a, b = synth_scalars(n, 78), synth_scalars(n, 79)
+    seed = bytes(range(32))
+    ms = []
+    for _ in range(3):
+        pf = ark_bp.bp_prove(curve, pts[:n], pts[n:2 * n], pts[2 * n:], a, b, seed)
+        ms.append(pf["prove_ms"])
+    best = min(ms)
+    ref_s = 527.8 if (log2n == 20 and curve == 0) else None  # analysis/main/data.csv:32 (unstated CPU)
+    return {"n": n, "prove_ms": best, "runs_ms": ms, "rounds": len(pf["ls"]), "proof_elements": 2 * (1 + len(pf["ls"])),
+            "reference_published_s": ref_s, "speedup_vs_reference_published": (ref_s * 1e3 / best) if ref_s else None,
+            "note": "host-resident inputs, upload + 2*log2(N) MSMs + folds + host Fiat-Shamir; reference number is from unknown CPU hardware"}
 
 
 def cpu_baseline(ffi, curve, pts, sc, log2s):
