@@ -145,7 +145,7 @@ def main():
     out = None
     if rank == 0:
         mad_peak = ffi.measure_mad_peak()
-        c_bits = args.window or max(2, min(16, args.log2n - 4))
+        c_bits = args.window or ffi.auto_window_bits(n)
         W = (256 + c_bits - 1) // c_bits
         accum_s = phase[3] * 1e-3
         algo_mads = W * n * MULS_PER_MIXED_ADD * MADS_PER_FIELD_MUL

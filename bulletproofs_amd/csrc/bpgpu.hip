@@ -76,7 +76,7 @@ struct Ctx {
   int num_cus = 256;
   float msm_ms[8] = {};
   // MSM workspace (grow-only)
-  DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy;
+  DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy, bcount;
   // staging for host-buffer entry points
   DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
   std::vector<uint32_t> h_winsum;
@@ -131,13 +131,32 @@ host::HPoint<BF> horner(const uint32_t* winsums, int W, int c) {
   return total;
 }
 
+// Window width.  Signed c-bit digits give 2^(c-1) buckets per window and W = ceil(256/c)
+// windows; about 32 points per bucket (c = log2 n - 4) balances bucket accumulation against the
+// bucket reduction.  The top window only holds 255 - (W-1)c significant bits; when that is a
+// handful, its few buckets each collect a large share of all points (handled by the heavy-bucket
+// path, but their bin is sorted by a single workgroup), so among the widths next to log2 n - 4
+// prefer one whose top window is well populated.
 int choose_window(uint32_t n) {
   if (g_ctx.window_bits) return g_ctx.window_bits;
   int lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
   int c = lg - 4;
   if (c < 2) c = 2;
-  if (c > 16) c = 16;
+  if (c > 20) c = 20;
+  if (lg >= 16) {
+    int best = -1, best_d = 99;
+    for (int cand = c - 2; cand <= c + 1 && cand <= 20; cand++) {
+      int W = (256 + cand - 1) / cand;
+      int top_bits = 255 - (W - 1) * cand;
+      int d = cand > c ? cand - c : c - cand;
+      if (top_bits >= 7 && d < best_d) {
+        best = cand;
+        best_d = d;
+      }
+    }
+    if (best > 0) c = best;
+  }
   return c;
 }
 
@@ -175,7 +194,8 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   if (lds_bytes > 64 * 1024) return fail(BPGPU_E_ARG, "window width %d needs %zu B of LDS bin counters", c, lds_bytes);
 
   TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2 + 64));  // bin_count | chunk counter | bin_cursor
-  TRY(C.cursor.ensure((size_t)(sp.nbins + 1) * 4));          // bin_start
+  TRY(C.cursor.ensure((size_t)(sp.nbins + 1) * 4 * 2));      // bin_start | tile_start
+  TRY(C.bcount.ensure((size_t)NB * 4));
   TRY(C.offs.ensure((size_t)(NB + 1) * 4));
   TRY(C.order.ensure((size_t)NB * 4));
   TRY(C.canon.ensure((size_t)slots * 32));
@@ -190,9 +210,12 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   uint32_t* bin_cursor = chunk_counter + 16;
   // heavy-bucket lists: at most entries/HEAVY_T heavy buckets and entries/HEAVY_PIECE + that many pieces
   const uint64_t entries = slots * W;
-  const size_t max_heavy = (size_t)(entries / HEAVY_T) + 1, max_pieces = (size_t)(entries / HEAVY_PIECE) + max_heavy;
+  const uint64_t mean_len = entries / NB;
+  const uint32_t heavy_t = (uint32_t)(4 * mean_len > HEAVY_T_MIN ? 4 * mean_len : HEAVY_T_MIN);
+  const size_t max_heavy = (size_t)(entries / heavy_t) + 1, max_pieces = (size_t)(entries / HEAVY_PIECE) + max_heavy;
   TRY(C.heavy.ensure((3 * max_heavy + 2 * max_pieces + 32 * max_pieces) * 4));
   HeavyLists hv;
+  hv.threshold = heavy_t;
   hv.counters = chunk_counter + 4;
   hv.bucket = C.heavy.as<uint32_t>();
   hv.piece0 = hv.bucket + max_heavy;
@@ -201,23 +224,28 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   hv.piece_hi = hv.piece_lo + max_pieces;
   hv.psum = hv.piece_hi + max_pieces;
   uint32_t* bin_start = C.cursor.as<uint32_t>();
+  uint32_t* tile_start = bin_start + sp.nbins + 1;
+  const uint32_t max_tiles = (uint32_t)(slots * W / BIN_TILE) + sp.nbins;
 
   hipStream_t st = C.stream;
   HIP_TRY(hipEventRecord(C.ev[0], st));
   HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4 + 64, st));
   k_part_count<SF><<<part_grid, 1024, lds_bytes, st>>>(plan, sp, d_scalars, C.canon.as<uint32_t>(), bin_count);
   HIP_TRY(hipEventRecord(C.ev[1], st));
-  k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, bin_cursor, sp.nbins);
+  k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, tile_start, bin_cursor, sp.nbins);
   k_part_scatter<<<part_grid, 1024, lds_bytes, st>>>(plan, sp, C.canon.as<uint32_t>(), bin_start, bin_cursor,
                                                      C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>());
   HIP_TRY(hipEventRecord(C.ev[2], st));
-  k_bin_sort<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
-                                        C.sorted.as<uint32_t>(), C.offs.as<uint32_t>(), C.order.as<uint32_t>(), hv);
+  HIP_TRY(hipMemsetAsync(C.bcount.p, 0, (size_t)NB * 4, st));
+  k_bin_count<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_fine.as<uint16_t>(), C.bcount.as<uint32_t>());
+  k_bin_offsets<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, C.bcount.as<uint32_t>(), C.offs.as<uint32_t>(),
+                                           C.order.as<uint32_t>(), hv);
+  k_bin_place<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
+                                          C.offs.as<uint32_t>(), C.bcount.as<uint32_t>(), C.sorted.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[3], st));
   k_accum<BF><<<C.num_cus * 2, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
-                                             C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits,
+                                             C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits, hv,
                                              chunk_counter);
-  k_accum_heavy<BF><<<C.num_cus * 2, 256, 0, st>>>(d_points, C.sorted.as<uint32_t>(), hv);
   k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[4], st));
   k_reduce1<BF><<<cdiv(nruns, 64), 64, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s, c - 1);
@@ -439,7 +467,7 @@ void bpgpu_shutdown(void) {
   if (!g_ctx.ready) return;
   (void)hipSetDevice(g_ctx.device);
   (void)hipStreamSynchronize(g_ctx.stream);
-  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial, &g_ctx.heavy,
+  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial, &g_ctx.heavy, &g_ctx.bcount,
                     &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip})
     b->release();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);

@@ -2,10 +2,11 @@
 // bpgpu.hip; arithmetic is in field.cuh / curve.cuh.
 //
 // MSM pipeline (reference algorithm being replaced: pippenger_msm, src/util/msm.rs:88-193):
-//   k_part_count / k_bin_scan / k_part_scatter / k_bin_sort
+//   k_part_count / k_bin_scan / k_part_scatter / k_bin_count / k_bin_offsets / k_bin_place
 //                    scalar -> canonical -> signed c-bit digits; two-level counting sort of
 //                    the (point, window) pairs by bucket (LDS histograms, see below)
-//   k_accum          one lane per bucket: mixed additions of its points (XYZZ accumulator)
+//   k_accum          persistent waves: one lane per bucket (one wave per piece of a heavy bucket),
+//                    mixed additions into an XYZZ accumulator; k_heavy_merge sums the pieces
 //   k_reduce1        one lane per run of S buckets: running-sum reduction (msm.rs:167-171)
 //   k_reduce2        one workgroup per window: tree-sum of the run results
 // The Horner combine over the W window sums (msm.rs:177-190) is a few hundred dependent
@@ -48,11 +49,12 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t (&w)[8], int pos
 //   k_part_count    digits -> per-workgroup LDS histogram of coarse bins -> bin_count
 //   k_bin_scan      exclusive scan of the bin counts (one small workgroup)
 //   k_part_scatter  digits again -> (index|sign, fine) entries appended to their bin
-//   k_bin_sort      one workgroup per bin: LDS counting sort by fine bucket -> sorted[], offs[]
+//   k_bin_count / k_bin_offsets / k_bin_place   counting sort of each bin by fine bucket -> sorted[], offs[]
 // ---------------------------------------------------------------------------
-constexpr uint32_t HEAVY_T = 128;       // longest list a single lane walks
-constexpr uint32_t HEAVY_PIECE = 2048;  // entries per wave-piece of a heavy bucket
+constexpr uint32_t HEAVY_T_MIN = 128;   // a single lane never walks a list longer than max(this, 4 x the mean)
+constexpr uint32_t HEAVY_PIECE = 1024;  // entries per wave-piece of a heavy bucket
 struct HeavyLists {
+  uint32_t threshold;  // lists longer than this are heavy
   uint32_t* counters;  // [0] heavy buckets, [1] pieces, [2] piece work counter (all zeroed per MSM)
   uint32_t* bucket;    // per heavy bucket: bucket id
   uint32_t* piece0;    //                   first piece
@@ -129,30 +131,47 @@ __global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, 
   }
 }
 
-// bin_start[0..nbins] = exclusive scan of bin_count; zeroes bin_cursor.  One workgroup.
+// bin_start[0..nbins] = exclusive scan of bin_count, tile_start[0..nbins] = exclusive scan of the
+// bins' tile counts (a tile = up to BIN_TILE entries of one bin); zeroes bin_cursor.  One workgroup.
+constexpr uint32_t BIN_TILE = 16384;
 __global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t* __restrict__ bin_count, uint32_t* __restrict__ bin_start,
-                                                   uint32_t* __restrict__ bin_cursor, uint32_t nbins) {
+                                                   uint32_t* __restrict__ tile_start, uint32_t* __restrict__ bin_cursor,
+                                                   uint32_t nbins) {
   __shared__ uint32_t part[1024];
+  __shared__ uint32_t tpart[1024];
   uint32_t tid = threadIdx.x;
   uint32_t per = (nbins + 1023) / 1024;
   uint32_t lo = min(tid * per, nbins), hi = min(lo + per, nbins);
-  uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += bin_count[(uint64_t)i * BIN_PAD];
+  uint32_t s = 0, ts = 0;
+  for (uint32_t i = lo; i < hi; i++) {
+    uint32_t v = bin_count[(uint64_t)i * BIN_PAD];
+    s += v;
+    ts += (v + BIN_TILE - 1) / BIN_TILE;
+  }
   part[tid] = s;
+  tpart[tid] = ts;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
     uint32_t v = tid >= d ? part[tid - d] : 0;
+    uint32_t tv = tid >= d ? tpart[tid - d] : 0;
     __syncthreads();
     part[tid] += v;
+    tpart[tid] += tv;
     __syncthreads();
   }
-  uint32_t run = part[tid] - s;
+  uint32_t run = part[tid] - s, trun = tpart[tid] - ts;
   for (uint32_t i = lo; i < hi; i++) {
+    uint32_t v = bin_count[(uint64_t)i * BIN_PAD];
     bin_start[i] = run;
+    tile_start[i] = trun;
     bin_cursor[(uint64_t)i * BIN_PAD] = 0;
-    run += bin_count[(uint64_t)i * BIN_PAD];
+    run += v;
+    trun += (v + BIN_TILE - 1) / BIN_TILE;
   }
-  if (tid == 1023) bin_start[nbins] = part[1023];
+  if (tid == 1023) {
+    bin_start[nbins] = part[1023];
+    tile_start[nbins] = tpart[1023];
+  }
 }
 
 __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp, const uint32_t* __restrict__ canon,
@@ -200,22 +219,52 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
   }
 }
 
-// One workgroup per coarse bin: counting sort of its entries by fine bucket, all counters in LDS.
-// Writes sorted[] (point index | sign) and the bucket offsets offs[bucket] (offs[nbuckets] = total).
-__global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* __restrict__ bin_start,
-                                                   const uint32_t* __restrict__ ent_idx,
-                                                   const uint16_t* __restrict__ ent_fine, uint32_t* __restrict__ sorted,
-                                                   uint32_t* __restrict__ offs, uint32_t* __restrict__ order, HeavyLists hv) {
+// Second level: counting sort of every bin by fine bucket.  A bin is cut into tiles of up to
+// BIN_TILE entries so that a bin holding a large share of all entries (the sparse top window, skewed
+// scalars) is spread over many workgroups; counters live in LDS, one global atomic per
+// (tile, non-empty fine bucket).
+//   k_bin_count    per tile: LDS histogram -> bcount[bucket]
+//   k_bin_offsets  per bin: scan -> offs[bucket]; bucket order by size; heavy-bucket lists
+//   k_bin_place    per tile: reserve a slice of each bucket, place the entries -> sorted[]
+__device__ __forceinline__ bool tile_lookup(const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ bin_start,
+                                            uint32_t nbins, uint32_t t, uint32_t& bin, uint32_t& lo, uint32_t& hi) {
+  if (t >= tile_start[nbins]) return false;
+  uint32_t a = 0, b = nbins;  // largest a with tile_start[a] <= t
+  while (b - a > 1) {
+    uint32_t mid = (a + b) >> 1;
+    if (tile_start[mid] <= t) a = mid; else b = mid;
+  }
+  bin = a;
+  lo = bin_start[a] + (t - tile_start[a]) * BIN_TILE;
+  uint32_t end = bin_start[a + 1];
+  hi = lo + BIN_TILE < end ? lo + BIN_TILE : end;
+  return true;
+}
+
+__global__ void __launch_bounds__(1024) k_bin_count(SortPlan sp, const uint32_t* __restrict__ bin_start,
+                                                    const uint32_t* __restrict__ tile_start,
+                                                    const uint16_t* __restrict__ ent_fine, uint32_t* __restrict__ bcount) {
   __shared__ uint32_t cnt[1024];
+  const uint32_t tid = threadIdx.x, F = 1u << sp.fine_bits;
+  uint32_t bin, lo, hi;
+  if (!tile_lookup(tile_start, bin_start, sp.nbins, blockIdx.x, bin, lo, hi)) return;  // uniform per workgroup
+  cnt[tid] = 0;
+  __syncthreads();
+  for (uint32_t e = lo + tid; e < hi; e += 1024) atomicAdd(&cnt[ent_fine[e]], 1u);
+  __syncthreads();
+  uint32_t v = cnt[tid];
+  if (tid < F && v) atomicAdd(&bcount[(uint64_t)bin * F + tid], v);
+}
+
+__global__ void __launch_bounds__(1024) k_bin_offsets(SortPlan sp, const uint32_t* __restrict__ bin_start,
+                                                      uint32_t* __restrict__ bcount, uint32_t* __restrict__ offs,
+                                                      uint32_t* __restrict__ order, HeavyLists hv) {
   __shared__ uint32_t part[1024];
   const uint32_t bin = blockIdx.x, tid = threadIdx.x;
   const uint32_t F = 1u << sp.fine_bits;
   const uint32_t bs = bin_start[bin], be = bin_start[bin + 1];
-  cnt[tid] = 0;
-  __syncthreads();
-  for (uint32_t e = bs + tid; e < be; e += 1024) atomicAdd(&cnt[ent_fine[e]], 1u);
-  __syncthreads();
-  uint32_t mine = cnt[tid];
+  uint32_t mine = tid < F ? bcount[(uint64_t)bin * F + tid] : 0u;
+  if (tid < F) bcount[(uint64_t)bin * F + tid] = 0;  // becomes k_bin_place's cursor
   part[tid] = mine;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -227,10 +276,9 @@ __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* 
   uint32_t start = bs + part[tid] - mine;
   if (tid < F) offs[(uint64_t)bin * F + tid] = start;
   if (bin == gridDim.x - 1 && tid == 0) offs[(uint64_t)gridDim.x * F] = be;
-  cnt[tid] = start;  // becomes the write cursor
-  // a bucket with more than HEAVY_T entries is cut into pieces of HEAVY_PIECE entries that whole
-  // waves accumulate (k_accum_heavy / k_heavy_merge); k_accum skips it
-  if (tid < F && mine > HEAVY_T) {
+  // a bucket with more than hv.threshold entries is cut into pieces of HEAVY_PIECE entries that whole
+  // waves accumulate; single lanes skip it
+  if (tid < F && mine > hv.threshold) {
     uint32_t np = (mine + HEAVY_PIECE - 1) / HEAVY_PIECE;
     uint32_t h = atomicAdd(&hv.counters[0], 1u);
     uint32_t p0 = atomicAdd(&hv.counters[1], np);
@@ -272,77 +320,31 @@ __global__ void __launch_bounds__(1024) k_bin_sort(SortPlan sp, const uint32_t* 
       order[(uint64_t)bin * F + pos] = bin * F + tid;
     }
   }
-  for (uint32_t e = bs + tid; e < be; e += 1024) {
-    uint32_t pos = atomicAdd(&cnt[ent_fine[e]], 1u);
-    sorted[pos] = ent_idx[e];
-  }
 }
 
-// Bucket accumulation.  BF = base field id.  Persistent waves: the grid is sized to the chip
-// (3 waves per SIMD) and every wave pulls chunks of 64 buckets from a shared counter until
-// none is left (each wave reaches chunk >= nchunks and leaves).  Chunks are handed out largest
-// first: chunk k is the (k / nbins)-th group of 64 buckets, in decreasing size, of bin
-// k % nbins (k_bin_sort's order[]), so lanes of a wave walk lists of near-equal length and the
-// kernel's tail is made of the shortest lists.
-template <int BF>
-__global__ void __launch_bounds__(256, 2) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
-                                               const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
-                                               uint32_t* __restrict__ bsum, uint32_t nbuckets, uint32_t nbins,
-                                               int fine_bits, uint32_t* __restrict__ chunk_counter) {
-  using E = Ec<BF>;
-  using IO = PointIo<BF>;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t nchunks = (nbuckets + 63u) >> 6;
-  const uint32_t F = 1u << fine_bits;
-  for (uint32_t it = 0; it <= nchunks; it++) {  // bounded: a wave can never pull more than every chunk
-    uint32_t k = 0;
-    if (lane == 0) k = atomicAdd(chunk_counter, 1u);
-    k = __builtin_amdgcn_readfirstlane(k);
-    if (k >= nchunks) break;
-    uint32_t gid;
-    if (F >= 64u) {
-      uint32_t pos = k / nbins, bin = k - pos * nbins;
-      gid = bin * F + pos * 64u + lane;
-    } else {
-      gid = k * 64u + lane;
-    }
-    // no lane may leave the loop body early: the chunk counter is read by lane 0 for the whole wave
-    bool act = gid < nbuckets;
-    uint32_t b = 0, lo = 0, hi = 0;
-    if (act) {
-      b = order[gid];
-      lo = offs[b];
-      hi = offs[b + 1];
-      act = hi - lo <= HEAVY_T;  // k_accum_heavy owns longer lists
-    }
-    if (!act) hi = lo;
-    Xyzz acc = E::identity();
-    // software pipeline: the index two entries ahead and the point one entry ahead are in
-    // flight while the current mixed add runs
-    uint32_t ent = lo < hi ? sorted[lo] : 0u;
-    uint32_t ent_n = lo + 1 < hi ? sorted[lo + 1] : 0u;
-    uint4 raw[4];
-    {
-      const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent & 0x7fffffffu));
-      raw[0] = pp[0]; raw[1] = pp[1]; raw[2] = pp[2]; raw[3] = pp[3];
-    }
-    for (uint32_t e = lo; e < hi; e++) {
-      uint32_t ent_nn = e + 2 < hi ? sorted[e + 2] : 0u;
-      uint4 nxt[4];
-      {
-        const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent_n & 0x7fffffffu));
-        nxt[0] = pp[0]; nxt[1] = pp[1]; nxt[2] = pp[2]; nxt[3] = pp[3];
-      }
-      uint32_t w[16] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w,
-                        raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
-      Aff q = IO::load_dev_affine(w);
-      if (ent >> 31) q = E::neg(q);
-      E::madd(acc, q);
-      ent = ent_n;
-      ent_n = ent_nn;
-      raw[0] = nxt[0]; raw[1] = nxt[1]; raw[2] = nxt[2]; raw[3] = nxt[3];
-    }
-    if (act) IO::store_dev_xyzz(bsum + 32ull * b, acc);
+__global__ void __launch_bounds__(1024) k_bin_place(SortPlan sp, const uint32_t* __restrict__ bin_start,
+                                                    const uint32_t* __restrict__ tile_start,
+                                                    const uint32_t* __restrict__ ent_idx,
+                                                    const uint16_t* __restrict__ ent_fine, const uint32_t* __restrict__ offs,
+                                                    uint32_t* __restrict__ bcursor, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t cnt[1024];
+  const uint32_t tid = threadIdx.x, F = 1u << sp.fine_bits;
+  uint32_t bin, lo, hi;
+  if (!tile_lookup(tile_start, bin_start, sp.nbins, blockIdx.x, bin, lo, hi)) return;
+  cnt[tid] = 0;
+  __syncthreads();
+  for (uint32_t e = lo + tid; e < hi; e += 1024) atomicAdd(&cnt[ent_fine[e]], 1u);
+  __syncthreads();
+  uint32_t v = cnt[tid];
+  __syncthreads();
+  if (tid < F) {
+    uint64_t bkt = (uint64_t)bin * F + tid;
+    cnt[tid] = offs[bkt] + (v ? atomicAdd(&bcursor[bkt], v) : 0u);  // this tile's slice of the bucket
+  }
+  __syncthreads();
+  for (uint32_t e = lo + tid; e < hi; e += 1024) {
+    uint32_t pos = atomicAdd(&cnt[ent_fine[e]], 1u);
+    sorted[pos] = ent_idx[e];
   }
 }
 
@@ -366,31 +368,89 @@ __device__ __forceinline__ Xyzz wave_sum_xyzz(Xyzz acc) {
   return acc;
 }
 
-// Heavy buckets (skewed scalars; also the top window, whose few significant bits leave it a
-// handful of buckets): persistent waves pull pieces of <= HEAVY_PIECE entries; the 64 lanes
-// stride through the piece and their partial sums are combined across the wave.
+// Bucket accumulation.  BF = base field id.  Persistent waves: the grid is sized to the chip
+// (2 waves per SIMD) and every wave pulls work items from a shared counter until none is left
+// (bounded loop; every wave reaches item >= total and leaves).  Items, longest first:
+//   * the pieces of heavy buckets (skewed scalars, or the top window whose few significant bits
+//     leave it a handful of buckets): the 64 lanes stride through <= HEAVY_PIECE entries and
+//     their partial sums are combined across the wave -> psum[piece];
+//   * chunks of 64 ordinary buckets, one per lane: chunk k is the (k / nbins)-th group of 64
+//     buckets, in decreasing size, of bin k % nbins (k_bin_offsets' order[]), so lanes of a wave
+//     walk lists of near-equal length and the kernel's tail is made of the shortest lists.
 template <int BF>
-__global__ void __launch_bounds__(256, 2) k_accum_heavy(const uint32_t* __restrict__ points,
-                                                        const uint32_t* __restrict__ sorted, HeavyLists hv) {
+__global__ void __launch_bounds__(256, 2) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
+                                               const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
+                                               uint32_t* __restrict__ bsum, uint32_t nbuckets, uint32_t nbins,
+                                               int fine_bits, HeavyLists hv, uint32_t* __restrict__ work_counter) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t nchunks = (nbuckets + 63u) >> 6;
   const uint32_t npieces = hv.counters[1];
-  for (uint32_t it = 0; it <= npieces; it++) {
-    uint32_t p = 0;
-    if (lane == 0) p = atomicAdd(&hv.counters[2], 1u);
-    p = __builtin_amdgcn_readfirstlane(p);
-    if (p >= npieces) break;
-    const uint32_t lo = hv.piece_lo[p], hi = hv.piece_hi[p];
+  const uint32_t total = npieces + nchunks;
+  const uint32_t F = 1u << fine_bits;
+  for (uint32_t it = 0; it <= total; it++) {  // bounded: a wave can never pull more than every item
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(work_counter, 1u);
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k >= total) break;
+    // no lane may leave the loop body early: the counter is read by lane 0 for the whole wave
+    const bool piece = k < npieces;
+    bool act = true;
+    uint32_t b = 0, lo = 0, hi = 0, step = 1;
+    if (piece) {
+      lo = hv.piece_lo[k] + lane;
+      hi = hv.piece_hi[k];
+      step = 64;
+    } else {
+      uint32_t kc = k - npieces, gid;
+      if (F >= 64u) {
+        uint32_t pos = kc / nbins, bin = kc - pos * nbins;
+        gid = bin * F + pos * 64u + lane;
+      } else {
+        gid = kc * 64u + lane;
+      }
+      act = gid < nbuckets;
+      if (act) {
+        b = order[gid];
+        lo = offs[b];
+        hi = offs[b + 1];
+        act = hi - lo <= hv.threshold;  // longer lists were cut into pieces
+      }
+      if (!act) hi = lo;
+    }
     Xyzz acc = E::identity();
-    for (uint32_t e = lo + lane; e < hi; e += 64) {
-      uint32_t ent = sorted[e];
-      Aff q = IO::load_dev_affine(points + 16ull * (ent & 0x7fffffffu));
+    // software pipeline: the index two entries ahead and the point one entry ahead are in
+    // flight while the current mixed add runs
+    uint32_t ent = lo < hi ? sorted[lo] : 0u;
+    uint32_t ent_n = lo + step < hi ? sorted[lo + step] : 0u;
+    uint4 raw[4];
+    {
+      const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent & 0x7fffffffu));
+      raw[0] = pp[0]; raw[1] = pp[1]; raw[2] = pp[2]; raw[3] = pp[3];
+    }
+    for (uint32_t e = lo; e < hi; e += step) {
+      uint32_t ent_nn = e + 2 * step < hi ? sorted[e + 2 * step] : 0u;
+      uint4 nxt[4];
+      {
+        const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent_n & 0x7fffffffu));
+        nxt[0] = pp[0]; nxt[1] = pp[1]; nxt[2] = pp[2]; nxt[3] = pp[3];
+      }
+      uint32_t w[16] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w,
+                        raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
+      Aff q = IO::load_dev_affine(w);
       if (ent >> 31) q = E::neg(q);
       E::madd(acc, q);
+      ent = ent_n;
+      ent_n = ent_nn;
+      raw[0] = nxt[0]; raw[1] = nxt[1]; raw[2] = nxt[2]; raw[3] = nxt[3];
     }
-    acc = wave_sum_xyzz<BF>(acc);
-    if (lane == 0) IO::store_dev_xyzz(hv.psum + 32ull * p, acc);
+    if (piece) {  // wave-uniform
+      acc = wave_sum_xyzz<BF>(acc);
+      if (lane == 0) IO::store_dev_xyzz(hv.psum + 32ull * k, acc);
+    } else if (act) {
+      IO::store_dev_xyzz(bsum + 32ull * b, acc);
+    }
   }
 }
 

@@ -224,6 +224,24 @@ def fold_points_device(curve, d_g, n_out, s_lo, s_hi, d_out=None):
     _check(load().bpgpu_fold_points_device(curve, d_g.ptr, n_out, _ptr(_u64(s_lo)), _ptr(_u64(s_hi)), d_out.ptr))
 
 
+def auto_window_bits(n: int) -> int:
+    """Window width the library picks for an n-point MSM (mirror of choose_window in bpgpu.hip;
+    reporting only -- the library does not take it from here)."""
+    lg = max(0, int(n).bit_length() - 1)
+    c = min(20, max(2, lg - 4))
+    if lg >= 16:
+        best, best_d = -1, 99
+        for cand in range(c - 2, min(20, c + 1) + 1):
+            W = (256 + cand - 1) // cand
+            top_bits = 255 - (W - 1) * cand
+            d = abs(cand - c)
+            if top_bits >= 7 and d < best_d:
+                best, best_d = cand, d
+        if best > 0:
+            c = best
+    return c
+
+
 def last_msm_timings():
     out = (c_float * 8)()
     _check(load().bpgpu_last_msm_timings(out))
