@@ -118,15 +118,26 @@ void write_xy_inf(const host::HPoint<BF>& p, uint64_t out[9]) {
   out[8] = finite ? 0 : 1;
 }
 
-// Horner combine, high window to low with c doublings per step (msm.rs:177-190)
+// Horner combine (msm.rs:177-190), high bit position to low with one doubling per position.
+// Window w contributes its component P at position c w and U_i at position c w + s + i
+// (kernels.cuh, bucket reduction); comps = 2 + nbits points per window (P comes in two halves), ark-form XYZZ words.
 template <int BF>
-host::HPoint<BF> horner(const uint32_t* winsums, int W, int c) {
+host::HPoint<BF> horner(const uint32_t* winsums, int W, int c, int s, int nbits) {
   using E = host::HEc<BF>;
+  const int comps = 2 + nbits;
   host::HPoint<BF> total = E::identity();
-  for (int j = W - 1; j >= 0; j--) {
-    if (j != W - 1)
-      for (int k = 0; k < c; k++) total = E::dbl(total);
-    total = E::add(total, hpoint_from_words<BF>(winsums + 32 * j));
+  const int top = c * (W - 1) + s + (nbits > 0 ? nbits - 1 : 0);
+  for (int pos = top; pos >= 0; pos--) {
+    total = E::dbl(total);
+    int w = pos / c, off = pos - w * c;
+    if (w >= W) continue;
+    if (off == 0) {
+      total = E::add(total, hpoint_from_words<BF>(winsums + 32 * (w * comps)));
+      total = E::add(total, hpoint_from_words<BF>(winsums + 32 * (w * comps + 1)));
+    }
+    // U_i of window w sits at off = s + i; with s = 0 and i = 0 it shares position c w with P
+    int i = off - s;
+    if (i >= 0 && i < nbits) total = E::add(total, hpoint_from_words<BF>(winsums + 32 * (w * comps + 2 + i)));
   }
   return total;
 }
@@ -178,11 +189,13 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const uint32_t B = 1u << (c - 1);
   const uint32_t NB = (uint32_t)plan.M * W * B;
   const uint64_t slots = (uint64_t)plan.M * plan.n;
-  // run length for the bucket reduction: aim at >= 64k lanes
-  int s = 0;
-  while ((NB >> s) > 65536u && s < c - 1) s++;
+  // bucket reduction: runs of S = 2^s buckets, at most 8192 runs per window
+  int s = c - 1 < 2 ? c - 1 : 2;
+  if (c - 1 - s > 13) s = c - 1 - 13;
   const uint32_t nruns = NB >> s;
   const uint32_t runs_per_window = B >> s;
+  const int nbits = c - 1 - s;  // bits of a window-local run index
+  const int comps = 2 + nbits;
 
   // two-level counting sort: coarse bins of 2^fine_bits buckets
   SortPlan sp;
@@ -203,8 +216,8 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   TRY(C.ent_fine.ensure((size_t)slots * W * 2 + 4));
   TRY(C.sorted.ensure((size_t)slots * W * 4 + 4));
   TRY(C.bsum.ensure((size_t)NB * 128));
-  TRY(C.partial.ensure((size_t)nruns * 128));
-  TRY(C.winsum.ensure((size_t)plan.M * W * 128));
+  TRY(C.partial.ensure((size_t)nruns * 256));
+  TRY(C.winsum.ensure((size_t)plan.M * W * comps * 128));
   uint32_t* bin_count = C.counts.as<uint32_t>();
   uint32_t* chunk_counter = bin_count + (size_t)sp.nbins * BIN_PAD;  // zeroed with bin_count
   uint32_t* bin_cursor = chunk_counter + 16;
@@ -248,16 +261,17 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
                                              chunk_counter);
   k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[4], st));
-  k_reduce1<BF><<<cdiv(nruns, 64), 64, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s, c - 1);
-  k_reduce2<BF><<<plan.M * W, 256, 0, st>>>(C.partial.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window);
+  k_reduce1<BF><<<cdiv(nruns, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
+  k_reduce2<BF><<<dim3(comps, plan.M * W), 512, 0, st>>>(C.partial.as<uint32_t>(), C.winsum.as<uint32_t>(),
+                                                          runs_per_window);
   HIP_TRY(hipEventRecord(C.ev[5], st));
-  C.h_winsum.resize((size_t)plan.M * W * 32);
-  HIP_TRY(hipMemcpyAsync(C.h_winsum.data(), C.winsum.p, (size_t)plan.M * W * 128, hipMemcpyDeviceToHost, st));
+  C.h_winsum.resize((size_t)plan.M * W * comps * 32);
+  HIP_TRY(hipMemcpyAsync(C.h_winsum.data(), C.winsum.p, (size_t)plan.M * W * comps * 128, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   auto t0 = std::chrono::steady_clock::now();
   for (int m = 0; m < plan.M; m++) {
-    host::HPoint<BF> r = horner<BF>(C.h_winsum.data() + (size_t)m * W * 32, W, c);
+    host::HPoint<BF> r = horner<BF>(C.h_winsum.data() + (size_t)m * W * comps * 32, W, c, s, nbits);
     write_xy_inf<BF>(r, out[m]);
   }
   auto t1 = std::chrono::steady_clock::now();

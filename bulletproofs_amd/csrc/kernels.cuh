@@ -7,9 +7,9 @@
 //                    the (point, window) pairs by bucket (LDS histograms, see below)
 //   k_accum          persistent waves: one lane per bucket (one wave per piece of a heavy bucket),
 //                    mixed additions into an XYZZ accumulator; k_heavy_merge sums the pieces
-//   k_reduce1        one lane per run of S buckets: running-sum reduction (msm.rs:167-171)
-//   k_reduce2        one workgroup per window: tree-sum of the run results
-// The Horner combine over the W window sums (msm.rs:177-190) is a few hundred dependent
+//   k_reduce1        one lane per run of S buckets: running sums (msm.rs:167-171) -> (T_r, S_r)
+//   k_reduce2        one workgroup per (window, component): tree-sums of T_r and of S_r by index bit
+// The Horner combine (msm.rs:177-190) over the windows' components is a few hundred dependent
 // group operations and runs on the host (host_field.h).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -348,12 +348,12 @@ __global__ void __launch_bounds__(1024) k_bin_place(SortPlan sp, const uint32_t*
   }
 }
 
-// sum over the 64 lanes of a wave, result valid in lane 0
-template <int BF>
+// sum over the first 2*FIRST lanes of a wave, result valid in lane 0
+template <int BF, int FIRST = 32>
 __device__ __forceinline__ Xyzz wave_sum_xyzz(Xyzz acc) {
   using E = Ec<BF>;
 #pragma unroll 1
-  for (int off = 32; off >= 1; off >>= 1) {
+  for (int off = FIRST; off >= 1; off >>= 1) {
     Xyzz o;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
@@ -471,59 +471,70 @@ __global__ void __launch_bounds__(256, 2) k_heavy_merge(HeavyLists hv, uint32_t*
   }
 }
 
-// One lane per run of S = 2^s consecutive buckets of one window.  With k0 the
-// window-local index of the run's first bucket (bucket k has weight k+1):
-//   sum_k (k+1) B_k = sum_k (k-k0+1) B_k + k0 * sum_k B_k
+// Bucket reduction (running-sum trick of msm.rs:167-171, restructured for depth): the window sum
+// sum_k (k+1) B_k is split by runs of S = 2^s consecutive buckets.  For run r (window-local) with
+// first bucket k0 = r S:
+//     sum_{k in run} (k+1) B_k = T_r + r S * S_r,   T_r = sum (k-k0+1) B_k,   S_r = sum B_k
+// k_reduce1: one lane per run, 2S additions, writes (T_r, S_r).
+// k_reduce2: sum_r r S_r = sum_i 2^i U_i with U_i = sum of S_r over runs whose index has bit i set;
+//            one workgroup per (window, component) tree-sums P = sum_r T_r or one U_i.
+// The host folds the components into its Horner pass at bit positions c w (P, in two halves) and
+// c w + s + i (U_i).
 template <int BF>
 __global__ void __launch_bounds__(256) k_reduce1(const uint32_t* __restrict__ bsum, uint32_t* __restrict__ partial,
-                                                 uint32_t nruns, int s, int cm1) {
+                                                 uint32_t nruns, int s) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nruns) return;
   uint32_t S = 1u << s;
   uint32_t first = r << s;
-  uint32_t k0 = first & ((1u << cm1) - 1u);
   Xyzz running = E::identity(), total = E::identity();
   for (int k = (int)S - 1; k >= 0; k--) {
     Xyzz bk = IO::load_dev_xyzz(bsum + 32ull * (first + k));
     running = E::add(running, bk);
     total = E::add(total, running);
   }
-  if (k0 != 0) {
-    Xyzz t = E::identity();
-    for (int bit = cm1 - 1; bit >= 0; bit--) {
-      t = E::dbl(t);
-      if ((k0 >> bit) & 1u) t = E::add(t, running);
-    }
-    total = E::add(total, t);
-  }
-  IO::store_dev_xyzz(partial + 32ull * r, total);
+  IO::store_dev_xyzz(partial + 64ull * r, total);
+  IO::store_dev_xyzz(partial + 64ull * r + 32, running);
 }
 
-// One workgroup per window: out[w] = sum of partial[w*per .. (w+1)*per), ark-form XYZZ.
+// grid = (2 + nbits, windows); components 0 and 1 = the two halves of P, component 2+i = U_i.
+// Every workgroup sums per/2 values: lanes first, then the wave, then the 8 waves.  out: ark-form XYZZ.
 template <int BF>
-__global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(512) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* __restrict__ out,
                                                  uint32_t per) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
-  __shared__ uint32_t sh[256 * 33];  // padded rows: 33 dwords per lane
-  uint32_t w = blockIdx.x, tid = threadIdx.x;
+  __shared__ uint32_t sh[8 * 33];
+  const uint32_t comp = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t half = per >> 1;  // per is a power of two; per = 1 leaves component 1.. empty
   Xyzz acc = E::identity();
-  for (uint32_t i = tid; i < per; i += 256) {
-    Xyzz p = IO::load_dev_xyzz(partial + 32ull * ((uint64_t)w * per + i));
-    acc = E::add(acc, p);
-  }
-  for (uint32_t d = 128; d >= 1; d >>= 1) {
-    __syncthreads();
-    if (tid >= d && tid < 2 * d) IO::store_dev_xyzz(sh + 33 * tid, acc);
-    __syncthreads();
-    if (tid < d) {
-      Xyzz p = IO::load_dev_xyzz(sh + 33 * (tid + d));
-      acc = E::add(acc, p);
+  if (per == 1) {
+    if (comp == 0 && tid == 0) acc = IO::load_dev_xyzz(partial + 64ull * w);
+  } else {
+    for (uint32_t j = tid; j < half; j += 512) {
+      uint32_t r, which;
+      if (comp < 2) {
+        r = comp * half + j;
+        which = 0;  // T_r
+      } else {
+        uint32_t i = comp - 2;  // runs whose index has bit i set
+        r = ((j >> i) << (i + 1)) | (1u << i) | (j & ((1u << i) - 1u));
+        which = 32;  // S_r
+      }
+      acc = E::add(acc, IO::load_dev_xyzz(partial + 64ull * ((uint64_t)w * per + r) + which));
     }
   }
-  if (tid == 0) IO::store_ark_xyzz(out + 32ull * w, acc);
+  acc = wave_sum_xyzz<BF>(acc);
+  if (lane == 0) IO::store_dev_xyzz(sh + 33 * wave, acc);
+  __syncthreads();
+  if (wave == 0) {
+    Xyzz p = E::identity();
+    if (lane < 8) p = IO::load_dev_xyzz(sh + 33 * lane);
+    p = wave_sum_xyzz<BF, 4>(p);
+    if (lane == 0) IO::store_ark_xyzz(out + 32ull * ((uint64_t)w * gridDim.x + comp), p);
+  }
 }
 
 // ---------------------------------------------------------------------------
