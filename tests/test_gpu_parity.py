@@ -169,3 +169,57 @@ def test_msm_skewed_scalars(ffi, c):
             ok = (int(got[8]) == 0 and (got[:8] == want[:8]).all()) or (int(got[8]) == 1 and not want[8:].any())
             assert ok, (name, bits)
     ffi.set_window_bits(0)
+
+
+def _xy(a):
+    return None if int(a[8]) else a[:8].tobytes()
+
+
+def test_msm_bench_recipe_2_16(ffi):
+    """BASELINE config 1/2 plumbing: the reference's own input recipe (examples/msm_bench.rs:40-44, one
+    test_rng stream: points then scalars) at 2^16, GPU vs the CPU restatement of pippenger_msm."""
+    from oracle import c_oracle as co
+    n = 1 << 16
+    pts, sc = co.msm_bench_inputs(0, n)
+    want = co.msm_pippenger(0, pts, sc, threads=16)
+    got = ffi.msm(0, pts, sc)
+    assert int(got[8]) == 0 and (got[:8] == want[:8]).all()
+    # device-resident entry point, same answer
+    d_p, d_s = ffi.points_to_device(0, pts), ffi.scalars_to_device(sc)
+    assert (ffi.msm_device(0, d_p, d_s, n) == got).all()
+    # round trip of the device point format
+    assert (ffi.points_from_device(0, d_p, 1000) == pts[:1000]).all()
+
+
+def test_msm_full_size_properties(ffi):
+    """At BASELINE's full size (2^20) the oracle is too slow for a unit test, so use size-independent
+    properties: linearity in the scalars, additivity over a split of the points (the multi-GPU shard
+    identity), invariance under a permutation of the pairs, and a 2^18 slice against the oracle."""
+    import bench
+    from oracle import c_oracle as co
+    n = 1 << 20
+    pts = bench.synth_points(ffi, 0, n, seed=11)
+    assert co.on_curve(0, pts[:: n // 64])
+    s, t = bench.synth_scalars(n, 12), bench.synth_scalars(n, 13)
+    d_p = ffi.points_to_device(0, pts)
+    ms = ffi.msm_device(0, d_p, ffi.scalars_to_device(s), n)
+    mt = ffi.msm_device(0, d_p, ffi.scalars_to_device(t), n)
+    # s + t mod r on the host (Montgomery form is linear): python ints, vectorised by limbs is overkill here
+    r = pm.PALLAS.r
+    si = [int.from_bytes(row.tobytes(), "little") for row in s]
+    ti = [int.from_bytes(row.tobytes(), "little") for row in t]
+    st = np.frombuffer(b"".join(((a + b) % r).to_bytes(32, "little") for a, b in zip(si, ti)), np.uint64).reshape(-1, 4)
+    mst = ffi.msm_device(0, d_p, ffi.scalars_to_device(st), n)
+    assert _xy(ffi.points_sum(0, np.stack([ms, mt]))) == _xy(mst)
+    # shard identity: the sum of the MSMs over two point ranges is the MSM over all points
+    h = 3 * n // 8
+    parts = [ffi.msm(0, pts[:h], s[:h]), ffi.msm(0, pts[h:], s[h:])]
+    assert _xy(ffi.points_sum(0, np.stack(parts))) == _xy(ms)
+    # permutation invariance
+    perm = np.random.default_rng(1).permutation(n)
+    assert _xy(ffi.msm(0, pts[perm], s[perm])) == _xy(ms)
+    # a 2^18 slice against the CPU restatement
+    k = 1 << 18
+    want = co.msm_pippenger(0, pts[:k], s[:k], threads=16)
+    got = ffi.msm(0, pts[:k], s[:k])
+    assert int(got[8]) == 0 and (got[:8] == want[:8]).all()
