@@ -78,7 +78,7 @@ struct Ctx {
   // MSM workspace (grow-only)
   DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy, bcount;
   // staging for host-buffer entry points
-  DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
+  DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip, fold_plans;
   std::vector<uint32_t> h_winsum;
 };
 
@@ -366,29 +366,19 @@ int fold_scalars_launch(int curve, uint32_t* v0, uint32_t* o0, const FoldScalars
   return 0;
 }
 
-// Joint sparse form (Solinas) of two canonical 256-bit scalars, as 4-bit codes.
+// ---- recoding of the two fold multipliers (shared by every lane of k_fold_points) -------------
 void shr1(uint64_t v[5]) {
   for (int i = 0; i < 4; i++) v[i] = (v[i] >> 1) | (v[i + 1] << 63);
   v[4] >>= 1;
 }
 bool nonzero(const uint64_t v[5]) { return (v[0] | v[1] | v[2] | v[3] | v[4]) != 0; }
 
-template <int SF>
-FoldPlan make_fold_plan(const uint64_t s_lo_ark[4], const uint64_t s_hi_ark[4]) {
-  using HFs = host::HF<SF>;
-  host::H4 a, b;
-  memcpy(a.v, s_lo_ark, 32);
-  memcpy(b.v, s_hi_ark, 32);
-  host::H4 ca = HFs::to_canon(a), cb = HFs::to_canon(b);
-  FoldPlan f;
-  memset(&f, 0, sizeof f);
-  memcpy(f.s_lo, ca.v, 32);
-  memcpy(f.s_hi, cb.v, 32);
-  uint64_t k0[5] = {ca.v[0], ca.v[1], ca.v[2], ca.v[3], 0};
-  uint64_t k1[5] = {cb.v[0], cb.v[1], cb.v[2], cb.v[3], 0};
+// Joint sparse form (Solinas) of two non-negative 256-bit integers as 4-bit codes; returns the length.
+int jsf_codes(const uint64_t a[4], const uint64_t b[4], uint32_t* codes, int max_positions) {
+  uint64_t k0[5] = {a[0], a[1], a[2], a[3], 0};
+  uint64_t k1[5] = {b[0], b[1], b[2], b[3], 0};
   int d0 = 0, d1 = 0, pos = 0;
-  while (nonzero(k0) || nonzero(k1) || d0 || d1) {
-    // l_i = d_i + k_i; only the low 3 bits matter
+  while ((nonzero(k0) || nonzero(k1) || d0 || d1) && pos < max_positions) {
     int l0 = (int)((k0[0] & 7) + d0) & 7, l1 = (int)((k1[0] & 7) + d1) & 7;
     int u0 = 0, u1 = 0;
     if (l0 & 1) {
@@ -407,28 +397,128 @@ FoldPlan make_fold_plan(const uint64_t s_lo_ark[4], const uint64_t s_hi_ark[4]) 
     if (u0 != 0 && u1 == 0) code = 1 | (u0 < 0 ? 8 : 0);
     else if (u0 == 0 && u1 != 0) code = 2 | (u1 < 0 ? 8 : 0);
     else if (u0 != 0 && u0 == u1) code = 3 | (u0 < 0 ? 8 : 0);
-    else if (u0 != 0) code = 4 | (u0 < 0 ? 8 : 0);  // u1 = -u0:  u0 (P - Q)
-    f.codes[pos >> 3] |= code << ((pos & 7) * 4);
+    else if (u0 != 0) code = 4 | (u0 < 0 ? 8 : 0);  // u1 = -u0:  u0 (first - second)
+    codes[pos >> 3] |= code << ((pos & 7) * 4);
     pos++;
   }
-  f.len = pos;
-  return f;
+  return pos;
+}
+
+// 256-bit wrapping helpers for the GLV split
+void mul256_wrap(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+  uint64_t r[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 carry = 0;
+    for (int j = 0; i + j < 4; j++) {
+      carry += (unsigned __int128)a[i] * b[j] + r[i + j];
+      r[i + j] = (uint64_t)carry;
+      carry >>= 64;
+    }
+  }
+  memcpy(out, r, 32);
+}
+void sub256_wrap(uint64_t a[4], const uint64_t b[4]) {
+  unsigned __int128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 d = (unsigned __int128)a[i] - b[i] - br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+void neg256_wrap(uint64_t a[4]) {
+  uint64_t z[4] = {0, 0, 0, 0};
+  sub256_wrap(z, a);
+  memcpy(a, z, 32);
+}
+// (k * g) >> 384 for a 4-limb k and a 5-limb g
+void mul_shift384(const uint64_t k[4], const uint64_t g[5], uint64_t out[4]) {
+  uint64_t r[9] = {0};
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 carry = 0;
+    for (int j = 0; j < 5; j++) {
+      carry += (unsigned __int128)k[i] * g[j] + r[i + j];
+      r[i + j] = (uint64_t)carry;
+      carry >>= 64;
+    }
+    r[i + 5] = (uint64_t)carry;
+  }
+  out[0] = r[6];
+  out[1] = r[7];
+  out[2] = r[8];
+  out[3] = 0;
+}
+
+// k (canonical, < r) = k1 + k2 lambda (mod r) with short k1, k2; magnitudes and signs out.
+template <int CURVE>
+void glv_split(const uint64_t k[4], uint64_t k1[4], bool& neg1, uint64_t k2[4], bool& neg2) {
+  using CC = CurveConsts<CURVE>;
+  uint64_t c1[4], c2[4], t[4];
+  mul_shift384(k, CC::GLV_G1, c1);
+  mul_shift384(k, CC::GLV_G2, c2);
+  if (CC::GLV_N1_NEG) neg256_wrap(c1);
+  if (CC::GLV_N2_NEG) neg256_wrap(c2);
+  memcpy(k1, k, 32);
+  mul256_wrap(c1, CC::GLV_A1, t);
+  sub256_wrap(k1, t);
+  mul256_wrap(c2, CC::GLV_A2, t);
+  sub256_wrap(k1, t);
+  memset(k2, 0, 32);
+  mul256_wrap(c1, CC::GLV_B1, t);
+  sub256_wrap(k2, t);
+  mul256_wrap(c2, CC::GLV_B2, t);
+  sub256_wrap(k2, t);
+  neg1 = (k1[3] >> 63) != 0;
+  neg2 = (k2[3] >> 63) != 0;
+  if (neg1) neg256_wrap(k1);
+  if (neg2) neg256_wrap(k2);
+}
+
+template <int CURVE>
+int make_fold_plan(const uint64_t s_lo_ark[4], const uint64_t s_hi_ark[4], FoldPlan& f) {
+  using HFs = host::HF<1 - CURVE>;
+  host::H4 a, b;
+  memcpy(a.v, s_lo_ark, 32);
+  memcpy(b.v, s_hi_ark, 32);
+  host::H4 ca = HFs::to_canon(a), cb = HFs::to_canon(b);
+  memset(&f, 0, sizeof f);
+  memcpy(f.s_lo, ca.v, 32);
+  memcpy(f.s_hi, cb.v, 32);
+  uint64_t k1[4], k2[4], l1[4], l2[4];
+  bool n1, n2, m1, m2;
+  glv_split<CURVE>(ca.v, k1, n1, k2, n2);
+  glv_split<CURVE>(cb.v, l1, m1, l2, m2);
+  // the halves must be short (they are < 2^129 by construction); anything else is a bug
+  if (k1[3] | k2[3] | l1[3] | l2[3] | (k1[2] >> 4) | (k2[2] >> 4) | (l1[2] >> 4) | (l2[2] >> 4))
+    return fail(BPGPU_E_STATE, "GLV split produced an over-long half");
+  f.neg = (n1 ? 1u : 0u) | (n2 ? 2u : 0u) | (m1 ? 4u : 0u) | (m2 ? 8u : 0u);
+  int lp = jsf_codes(k1, k2, f.codes_p, 136), lq = jsf_codes(l1, l2, f.codes_q, 136);
+  f.len = lp > lq ? lp : lq;
+  return 0;
 }
 
 int fold_points_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64_t lo0[4], const uint64_t hi0[4],
                        const uint32_t* g1, uint32_t* o1, const uint64_t lo1[4], const uint64_t hi1[4], int nvec,
                        uint32_t n) {
   if (n == 0) return 0;
-  dim3 grid(cdiv(n, 64), nvec);
+  Ctx& C = g_ctx;
+  FoldPlan plans[2];
   if (curve == BPGPU_PALLAS) {
-    FoldPlan f0 = make_fold_plan<1>(lo0, hi0);
-    FoldPlan f1 = nvec > 1 ? make_fold_plan<1>(lo1, hi1) : f0;
-    k_fold_points<0><<<grid, 64, 0, g_ctx.stream>>>(g0, o0, f0, g1, o1, f1, n);
+    TRY(make_fold_plan<0>(lo0, hi0, plans[0]));
+    TRY(make_fold_plan<0>(nvec > 1 ? lo1 : lo0, nvec > 1 ? hi1 : hi0, plans[1]));
   } else {
-    FoldPlan f0 = make_fold_plan<0>(lo0, hi0);
-    FoldPlan f1 = nvec > 1 ? make_fold_plan<0>(lo1, hi1) : f0;
-    k_fold_points<1><<<grid, 64, 0, g_ctx.stream>>>(g0, o0, f0, g1, o1, f1, n);
+    TRY(make_fold_plan<1>(lo0, hi0, plans[0]));
+    TRY(make_fold_plan<1>(nvec > 1 ? lo1 : lo0, nvec > 1 ? hi1 : hi0, plans[1]));
   }
+  // the plans travel through a small device buffer (stream-ordered copy from pinned-by-value staging)
+  TRY(C.fold_plans.ensure(sizeof plans));
+  HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
+  HIP_TRY(hipMemcpyAsync(C.fold_plans.p, plans, sizeof plans, hipMemcpyHostToDevice, C.stream));
+  HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
+  dim3 grid(cdiv(n, 64), nvec);
+  if (curve == BPGPU_PALLAS)
+    k_fold_points<0><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<FoldPlan>(), n);
+  else
+    k_fold_points<1><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<FoldPlan>(), n);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -482,7 +572,7 @@ void bpgpu_shutdown(void) {
   (void)hipSetDevice(g_ctx.device);
   (void)hipStreamSynchronize(g_ctx.stream);
   for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial, &g_ctx.heavy, &g_ctx.bcount,
-                    &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip})
+                    &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip, &g_ctx.fold_plans})
     b->release();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(g_ctx.stream);

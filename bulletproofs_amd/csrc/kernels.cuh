@@ -738,20 +738,27 @@ __global__ void __launch_bounds__(256) k_fold_scalars(uint32_t* __restrict__ v0,
 }
 
 // ---------------------------------------------------------------------------
-// Generator fold (base field BF):  out[i] = s_lo * g[i] + s_hi * g[i+n]
-// (bp_iter.rs:97-104).  Every lane uses the same two scalars, so the joint sparse form
-// of (s_lo, s_hi) is recoded once on the host and the whole grid follows one
-// branch-uniform double-and-add schedule: 4-bit codes, most significant first,
-//   code & 7: 0 none, 1 P, 2 Q, 3 P+Q, 4 P-Q;  code & 8: negate.
+// Generator fold (base field BF = curve id):  out[i] = s_lo * g[i] + s_hi * g[i+n]
+// (bp_iter.rs:97-104).  Every lane uses the same two scalars, so they are recoded once on the
+// host and the whole grid follows one branch-uniform schedule:
+//   * GLV: the curve has the endomorphism phi(x, y) = (zeta x, y) = [lambda](x, y), so
+//     s = k1 + k2 lambda with |k1|, |k2| < 2^129 halves the doublings:
+//         s_lo P + s_hi Q = k1 P + k2 phi(P) + l1 Q + l2 phi(Q)
+//   * each pair (|k1|, |k2|), (|l1|, |l2|) is written in joint sparse form (half the positions
+//     are zero); signs of the halves are applied to the base points.
+// 4-bit codes, position 0 = least significant:  code & 7: 0 none, 1 first base, 2 second base,
+// 3 first + second, 4 first - second;  code & 8: negate.
 // ---------------------------------------------------------------------------
 struct FoldPlan {
-  uint32_t codes[33];  // up to 257 positions, 8 per word, position 0 = least significant
+  uint32_t codes_p[17];  // pair (P, phi P), up to 136 positions, 8 per word
+  uint32_t codes_q[17];  // pair (Q, phi Q)
   int len;
+  uint32_t neg;               // bit 0: k1 < 0, bit 1: k2 < 0, bit 2: l1 < 0, bit 3: l2 < 0
   uint32_t s_lo[8], s_hi[8];  // canonical scalars (slow path only)
 };
 
 template <int BF>
-__device__ Xyzz mul_bits(const Aff& p, const uint32_t (&k)[8]) {
+__device__ __attribute__((noinline)) Xyzz mul_bits(const Aff& p, const uint32_t* k) {
   using E = Ec<BF>;
   Xyzz acc = E::identity();
   for (int i = 255; i >= 0; i--) {
@@ -761,10 +768,26 @@ __device__ Xyzz mul_bits(const Aff& p, const uint32_t (&k)[8]) {
   return acc;
 }
 
+// a + b and a - b in affine for two finite points with different x, given inv = 1 / (b.x - a.x)
+template <int BF>
+__device__ __forceinline__ void affine_sum_diff(const Aff& a, const Aff& b, const Fe& inv, Aff& sum, Aff& dif) {
+  using F = Fp<BF>;
+  Fe lam = F::mul(F::sub(b.y, a.y), inv);
+  Fe x3 = F::carry(F::sub(F::sub(F::sqr(lam), a.x), b.x));
+  sum.x = x3;
+  sum.y = F::carry(F::sub(F::mul(lam, F::sub(a.x, x3)), a.y));
+  sum.inf = false;
+  Fe lam2 = F::mul(F::neg(F::add(b.y, a.y)), inv);
+  Fe x4 = F::carry(F::sub(F::sub(F::sqr(lam2), a.x), b.x));
+  dif.x = x4;
+  dif.y = F::carry(F::sub(F::mul(lam2, F::sub(a.x, x4)), a.y));
+  dif.inf = false;
+}
+
 template <int BF>
 __global__ void __launch_bounds__(256) k_fold_points(const uint32_t* __restrict__ g0, uint32_t* __restrict__ o0,
-                                                     FoldPlan f0, const uint32_t* __restrict__ g1,
-                                                     uint32_t* __restrict__ o1, FoldPlan f1, uint32_t n) {
+                                                     const uint32_t* __restrict__ g1, uint32_t* __restrict__ o1,
+                                                     const FoldPlan* __restrict__ plans, uint32_t n) {
   using F = Fp<BF>;
   using E = Ec<BF>;
   using IO = PointIo<BF>;
@@ -772,41 +795,51 @@ __global__ void __launch_bounds__(256) k_fold_points(const uint32_t* __restrict_
   if (i >= n) return;
   const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
-  const FoldPlan& f = blockIdx.y == 0 ? f0 : f1;
+  const FoldPlan* f = plans + blockIdx.y;
   Aff P = IO::load_dev_affine(g + 16ull * i);
   Aff Q = IO::load_dev_affine(g + 16ull * (i + n));
-  Fe dx = F::sub(Q.x, P.x);
   Xyzz acc;
-  if (P.inf || Q.inf || F::is_zero(dx)) {
-    // padding (identity) or P = +-Q: two independent ladders
-    Xyzz r1 = mul_bits<BF>(P, f.s_lo);
-    Xyzz r2 = mul_bits<BF>(Q, f.s_hi);
+  if (P.inf || Q.inf) {
+    // padding (identity points): two independent double-and-add ladders
+    Xyzz r1 = mul_bits<BF>(P, f->s_lo);
+    Xyzz r2 = mul_bits<BF>(Q, f->s_hi);
     acc = E::add(r1, r2);
   } else {
-    // P+Q and P-Q in affine, sharing the inversion of (xQ - xP)
-    Fe inv = F::inv(dx);
-    Aff S, D;
-    {
-      Fe lam = F::mul(F::sub(Q.y, P.y), inv);
-      Fe x3 = F::carry(F::sub(F::sub(F::sqr(lam), P.x), Q.x));
-      S.x = x3;
-      S.y = F::carry(F::sub(F::mul(lam, F::sub(P.x, x3)), P.y));
-      S.inf = false;
-      Fe lam2 = F::mul(F::neg(F::add(Q.y, P.y)), inv);
-      Fe x4 = F::carry(F::sub(F::sub(F::sqr(lam2), P.x), Q.x));
-      D.x = x4;
-      D.y = F::carry(F::sub(F::mul(lam2, F::sub(P.x, x4)), P.y));
-      D.inf = false;
-    }
+    const uint32_t neg = f->neg;
+    const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
+    // table: T[0..3] = P1, P2 = phi(P1), P1 + P2, P1 - P2 (signs of k1, k2 applied); T[4..7] same for Q
+    Aff T[8];
+    T[0] = P;
+    T[1].x = F::mul(P.x, zeta);
+    T[1].y = P.y;
+    T[1].inf = false;
+    T[4] = Q;
+    T[5].x = F::mul(Q.x, zeta);
+    T[5].y = Q.y;
+    T[5].inf = false;
+    if (neg & 1u) T[0].y = F::carry(F::neg(T[0].y));
+    if (neg & 2u) T[1].y = F::carry(F::neg(T[1].y));
+    if (neg & 4u) T[4].y = F::carry(F::neg(T[4].y));
+    if (neg & 8u) T[5].y = F::carry(F::neg(T[5].y));
+    // x never vanishes on a prime-order curve y^2 = x^3 + 5, so zeta x != x: one shared inversion
+    Fe dp = F::carry(F::sub(T[1].x, T[0].x)), dq = F::carry(F::sub(T[5].x, T[4].x));
+    Fe ti = F::inv(F::mul(dp, dq));
+    affine_sum_diff<BF>(T[0], T[1], F::mul(ti, dq), T[2], T[3]);
+    affine_sum_diff<BF>(T[4], T[5], F::mul(ti, dp), T[6], T[7]);
     acc = E::identity();
-    for (int pos = f.len - 1; pos >= 0; pos--) {
+    for (int pos = f->len - 1; pos >= 0; pos--) {
       acc = E::dbl(acc);
-      uint32_t code = (f.codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;
-      uint32_t sel = code & 7u;
-      if (sel) {
-        Aff t = sel == 1 ? P : (sel == 2 ? Q : (sel == 3 ? S : D));
-        if (code & 8u) t = E::neg(t);
-        E::madd(acc, t);
+      const uint32_t cp = (f->codes_p[pos >> 3] >> ((pos & 7) * 4)) & 15u;
+      const uint32_t cq = (f->codes_q[pos >> 3] >> ((pos & 7) * 4)) & 15u;
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {
+        const uint32_t code = h ? cq : cp;
+        const uint32_t sel = code & 7u;
+        if (sel) {
+          Aff t = T[4 * h + (int)sel - 1];
+          if (code & 8u) t = E::neg(t);
+          E::madd(acc, t);
+        }
       }
     }
   }

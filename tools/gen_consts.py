@@ -75,6 +75,104 @@ def emit_field(fid, p, name):
     return "\n".join(out)
 
 
+def limbs64n(v, n):
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+
+
+def isqrt(n):
+    import math
+    return math.isqrt(n)
+
+
+def glv_basis(r, lam):
+    """Short basis of the lattice {(a, b): a + b*lam = 0 mod r} by the extended Euclidean algorithm."""
+    seq = [(r, 0), (lam, 1)]  # (remainder, t) with remainder = s*r + t*lam
+    while seq[-1][0] != 0:
+        q = seq[-2][0] // seq[-1][0]
+        seq.append((seq[-2][0] - q * seq[-1][0], seq[-2][1] - q * seq[-1][1]))
+    rt = isqrt(r)
+    l = max(i for i, (rem, _) in enumerate(seq) if rem >= rt)
+    a1, b1 = seq[l + 1][0], -seq[l + 1][1]
+    cands = [(seq[l][0], -seq[l][1]), (seq[l + 2][0], -seq[l + 2][1])]
+    a2, b2 = min(cands, key=lambda v: v[0] * v[0] + v[1] * v[1])
+    for a, b in ((a1, b1), (a2, b2)):
+        assert (a + b * lam) % r == 0
+    return a1, b1, a2, b2
+
+
+def glv_split(k, r, a1, b1, a2, b2, g1, g2, n1neg, n2neg):
+    """What the host code does: c_i = +-((k * g_i) >> 384); (k1, k2) = (k, 0) - c1 (a1, b1) - c2 (a2, b2)."""
+    c1 = (k * g1) >> 384
+    c2 = (k * g2) >> 384
+    if n1neg:
+        c1 = -c1
+    if n2neg:
+        c2 = -c2
+    return k - c1 * a1 - c2 * a2, -c1 * b1 - c2 * b2
+
+
+def emit_curve(cid, q, r, name):
+    """GLV constants of curve cid: base field q, scalar field r, endomorphism (x, y) -> (zeta x, y) = [lambda](x, y)."""
+    import random
+    # the matching pair (zeta, lambda): checked on the generator (-1, 2) with an affine ladder
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        x1, y1 = P
+        x2, y2 = Q
+        if x1 == x2:
+            if (y1 + y2) % q == 0:
+                return None
+            m = 3 * x1 * x1 * pow(2 * y1, -1, q) % q
+        else:
+            m = (y2 - y1) * pow(x2 - x1, -1, q) % q
+        x3 = (m * m - x1 - x2) % q
+        return (x3, (m * (x1 - x3) - y1) % q)
+
+    def mul(P, k):
+        acc = None
+        for i in range(k.bit_length() - 1, -1, -1):
+            acc = add(acc, acc)
+            if (k >> i) & 1:
+                acc = add(acc, P)
+        return acc
+
+    zeta = cube_root_of_unity(q)
+    G = (q - 1, 2)
+    lam = cube_root_of_unity(r)
+    if mul(G, lam) != (zeta * G[0] % q, G[1]):
+        lam = lam * lam % r
+    assert mul(G, lam) == (zeta * G[0] % q, G[1])
+    a1, b1, a2, b2 = glv_basis(r, lam)
+    n1, n2 = b2, -b1
+    g1 = ((abs(n1) << 384) + r // 2) // r
+    g2 = ((abs(n2) << 384) + r // 2) // r
+    rnd = random.Random(cid)
+    worst = 0
+    for _ in range(2000):
+        k = rnd.randrange(r)
+        k1, k2 = glv_split(k, r, a1, b1, a2, b2, g1, g2, n1 < 0, n2 < 0)
+        assert (k1 + k2 * lam - k) % r == 0
+        worst = max(worst, abs(k1).bit_length(), abs(k2).bit_length())
+    assert worst <= 129, worst
+    M = (1 << 256) - 1
+    out = []
+    out.append(f"// {name}: endomorphism (x, y) -> (zeta x, y) = [lambda](x, y); GLV halves are at most {worst} bits")
+    out.append(f"template <> struct CurveConsts<{cid}> {{")
+    out.append(f"  static constexpr uint32_t ZETA261[9] = {arr(limbs29(zeta * (1 << 261) % q), '0x%08xu')};")
+    out.append(f"  static constexpr uint64_t LAMBDA[4] = {arr(limbs64(lam), '0x%016xull')};  // canonical")
+    for nm, v in (("A1", a1), ("B1", b1), ("A2", a2), ("B2", b2)):
+        out.append(f"  static constexpr uint64_t GLV_{nm}[4] = {arr(limbs64(v & M), '0x%016xull')};  // two's complement, = {v}")
+    out.append(f"  static constexpr uint64_t GLV_G1[5] = {arr(limbs64n(g1, 5), '0x%016xull')};  // round(2^384 |b2| / r)")
+    out.append(f"  static constexpr uint64_t GLV_G2[5] = {arr(limbs64n(g2, 5), '0x%016xull')};  // round(2^384 |b1| / r)")
+    out.append(f"  static constexpr bool GLV_N1_NEG = {'true' if n1 < 0 else 'false'};")
+    out.append(f"  static constexpr bool GLV_N2_NEG = {'true' if n2 < 0 else 'false'};")
+    out.append("};")
+    return "\n".join(out)
+
+
 def main():
     hdr = []
     hdr.append("// GENERATED by tools/gen_consts.py -- do not edit.")
@@ -86,6 +184,9 @@ def main():
     hdr.append(emit_field(0, P0, "field 0 = Pallas base field Fq = Vesta scalar field"))
     hdr.append(emit_field(1, P1, "field 1 = Pallas scalar field Fr = Vesta base field"))
     hdr.append("// Curve c (0 = Pallas, 1 = Vesta): base field id = c, scalar field id = 1 - c.")
+    hdr.append("template <int CURVE> struct CurveConsts;")
+    hdr.append(emit_curve(0, P0, P1, "Pallas"))
+    hdr.append(emit_curve(1, P1, P0, "Vesta"))
     hdr.append("}  // namespace bpgpu")
     path = os.path.join(os.path.dirname(__file__), "..", "bulletproofs_amd", "csrc", "pasta_consts.h")
     os.makedirs(os.path.dirname(path), exist_ok=True)
