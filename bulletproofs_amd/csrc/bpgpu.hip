@@ -3,6 +3,7 @@
 // normalisation, joint-sparse-form recoding) in host_field.h.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -73,6 +74,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
   int window_bits = 0;
+  size_t freeze_len = 1u << 15;  // vectors this short defer the generator fold (0 = never)
   int num_cus = 256;
   float msm_ms[8] = {};
   // MSM workspace (grow-only)
@@ -537,10 +539,53 @@ struct bpgpu_ipa {
   size_t len;  // current vector length
   // points: A at [0, np), B at [np, 2np), Q at 2np           (dev affine, 64 B each)
   // scalars: a at [0, np), b at [np, 2np), c_L at 2np, c_R at 2np+1 (ark form, 32 B each)
+  //          then (when short rounds defer the generator fold) 4 n0 MSM scalars and 2 n0 weights
   uint32_t* d_pts;
   uint32_t* d_sc;
   bool lr_done;
+  // deferred generator folding (kernels.cuh, k_frozen_*)
+  size_t freeze_cap;  // room reserved: n0 <= freeze_cap
+  bool frozen;
+  bool freeze_disabled;
+  size_t n0;  // length at which the generators stopped being folded
+  std::vector<std::array<uint64_t, 8>> pending;  // (x, x^-1) of the folds not applied to the points
+  uint32_t* fsc() const { return d_sc + 8ull * (2 * np + 2); }
+  uint32_t* wA() const { return fsc() + 8ull * 4 * freeze_cap; }
+  uint32_t* wB() const { return wA() + 8ull * freeze_cap; }
 };
+
+namespace {
+// stop folding the generators: they stay as they are now (length s->len) and weights start at one
+int ipa_freeze(bpgpu_ipa* s) {
+  s->n0 = s->len;
+  s->frozen = true;
+  s->pending.clear();
+  const uint32_t cnt = (uint32_t)(2 * s->freeze_cap);
+  if (s->curve == BPGPU_PALLAS)
+    k_frozen_init<1><<<cdiv(cnt, 256), 256, 0, g_ctx.stream>>>(s->wA(), cnt);
+  else
+    k_frozen_init<0><<<cdiv(cnt, 256), 256, 0, g_ctx.stream>>>(s->wA(), cnt);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// apply the deferred point folds (export needs the folded generators themselves)
+int ipa_materialise(bpgpu_ipa* s) {
+  if (!s->frozen) return 0;
+  size_t len = s->n0;
+  uint32_t* dA = s->d_pts;
+  uint32_t* dB = s->d_pts + 16ull * s->np;
+  for (const auto& ch : s->pending) {
+    const uint64_t* x = ch.data();
+    const uint64_t* xi = ch.data() + 4;
+    TRY(fold_points_launch(s->curve, dA, dA, xi, x, dB, dB, x, xi, 2, (uint32_t)(len / 2)));
+    len /= 2;
+  }
+  s->pending.clear();
+  s->frozen = false;
+  s->freeze_disabled = true;
+  return 0;
+}
+}  // namespace
 
 extern "C" {
 
@@ -582,6 +627,12 @@ void bpgpu_shutdown(void) {
 int bpgpu_set_window_bits(int c) {
   if (c != 0 && (c < 2 || c > 20)) return fail(BPGPU_E_ARG, "window bits %d outside [2, 20]", c);
   g_ctx.window_bits = c;
+  return 0;
+}
+
+int bpgpu_set_freeze_len(size_t len) {
+  if (len > (1u << 24)) return fail(BPGPU_E_ARG, "freeze length too large");
+  g_ctx.freeze_len = len;
   return 0;
 }
 
@@ -818,13 +869,18 @@ int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gen
   s->lr_done = false;
   s->d_pts = nullptr;
   s->d_sc = nullptr;
+  s->freeze_cap = np < g_ctx.freeze_len ? np : g_ctx.freeze_len;
+  s->frozen = false;
+  s->freeze_disabled = g_ctx.freeze_len == 0;
+  s->n0 = 0;
+  const size_t sc_words = (2 * np + 2 + 6 * s->freeze_cap) * 8;
   auto cleanup = [&]() {
     if (s->d_pts) (void)hipFree(s->d_pts);
     if (s->d_sc) (void)hipFree(s->d_sc);
     delete s;
   };
   hipError_t e = hipMalloc((void**)&s->d_pts, (2 * np + 1) * 64);
-  if (e == hipSuccess) e = hipMalloc((void**)&s->d_sc, (2 * np + 2) * 32);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_sc, sc_words * 4);
   if (e != hipSuccess) {
     cleanup();
     return fail(BPGPU_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -834,7 +890,7 @@ int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gen
   do {
     // identity points / zero scalars are all-zero bytes in both device formats
     if (hipMemsetAsync(s->d_pts, 0, (2 * np + 1) * 64, st) != hipSuccess ||
-        hipMemsetAsync(s->d_sc, 0, (2 * np + 2) * 32, st) != hipSuccess) {
+        hipMemsetAsync(s->d_sc, 0, sc_words * 4, st) != hipSuccess) {
       rc = fail(BPGPU_E_HIP, "hipMemsetAsync failed");
       break;
     }
@@ -856,6 +912,7 @@ int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gen
     if ((rc = points_in(curve, (uint32_t*)stg, s->d_pts, n, 0)) != 0) break;
     if ((rc = points_in(curve, (uint32_t*)(stg + n * 96), s->d_pts + 16 * np, n, 0)) != 0) break;
     if ((rc = points_in(curve, (uint32_t*)(stg + 2 * n * 96), s->d_pts + 32 * np, 1, 0)) != 0) break;
+    if (np <= s->freeze_cap && !s->freeze_disabled && np > 1 && (rc = ipa_freeze(s)) != 0) break;
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(BPGPU_E_HIP, "sync failed");
   } while (0);
   if (rc) {
@@ -881,6 +938,29 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
   MsmPlan plan;
   memset(&plan, 0, sizeof plan);
   plan.M = 2;
+  uint64_t out[2][9];
+  if (s->frozen) {
+    const uint32_t n0 = (uint32_t)s->n0, fs = 2 * np + 2;
+    if (s->curve == BPGPU_PALLAS)
+      k_frozen_scalars<1><<<cdiv(n0, 256), 256, 0, g_ctx.stream>>>(s->d_sc, s->d_sc + 8ull * np, s->wA(), s->wB(), s->fsc(),
+                                                                n0, n);
+    else
+      k_frozen_scalars<0><<<cdiv(n0, 256), 256, 0, g_ctx.stream>>>(s->d_sc, s->d_sc + 8ull * np, s->wA(), s->wB(), s->fsc(),
+                                                                n0, n);
+    HIP_TRY(hipGetLastError());
+    plan.n = 2 * n0 + 1;
+    plan.seg[0][0] = MsmSeg{0u, fs, n0};
+    plan.seg[0][1] = MsmSeg{np, fs + n0, n0};
+    plan.seg[0][2] = MsmSeg{2 * np, 2 * np, 1};
+    plan.seg[1][0] = MsmSeg{0u, fs + 2 * n0, n0};
+    plan.seg[1][1] = MsmSeg{np, fs + 3 * n0, n0};
+    plan.seg[1][2] = MsmSeg{2 * np, 2 * np + 1, 1};
+    TRY(msm_dispatch(s->curve, s->d_pts, s->d_sc, plan, out));
+    memcpy(l_xy_inf, out[0], 72);
+    memcpy(r_xy_inf, out[1], 72);
+    s->lr_done = true;
+    return 0;
+  }
   plan.n = 2 * n + 1;
   // L = msm(A[n..] | B[..n] | Q,  a[..n] | b[n..] | c_L)   (bp_iter.rs:68-74)
   plan.seg[0][0] = MsmSeg{n, 0u, n};
@@ -890,7 +970,6 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
   plan.seg[1][0] = MsmSeg{0u, n, n};
   plan.seg[1][1] = MsmSeg{np + n, np, n};
   plan.seg[1][2] = MsmSeg{2 * np, 2 * np + 1, 1};
-  uint64_t out[2][9];
   TRY(msm_dispatch(s->curve, s->d_pts, s->d_sc, plan, out));
   memcpy(l_xy_inf, out[0], 72);
   memcpy(r_xy_inf, out[1], 72);
@@ -910,12 +989,27 @@ int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv
   uint32_t* db = s->d_sc + 8ull * np;
   TRY(fold_scalars_launch(s->curve, da, da, fa, db, db, fb, 2, n));
   // A' = x^-1 A_lo + x A_hi;  B' = x B_lo + x^-1 B_hi          (bp_iter.rs:97-104)
-  uint32_t* dA = s->d_pts;
-  uint32_t* dB = s->d_pts + 16ull * np;
-  TRY(fold_points_launch(s->curve, dA, dA, x_inv, x, dB, dB, x, x_inv, 2, n));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  if (s->frozen) {
+    // deferred: the fold only updates the weights of the frozen generators
+    const uint32_t n0 = (uint32_t)s->n0;
+    if (s->curve == BPGPU_PALLAS)
+      k_frozen_update<1><<<cdiv(n0, 256), 256, 0, g_ctx.stream>>>(s->wA(), s->wB(), n0, n, fa);
+    else
+      k_frozen_update<0><<<cdiv(n0, 256), 256, 0, g_ctx.stream>>>(s->wA(), s->wB(), n0, n, fa);
+    HIP_TRY(hipGetLastError());
+    std::array<uint64_t, 8> ch;
+    memcpy(ch.data(), x, 32);
+    memcpy(ch.data() + 4, x_inv, 32);
+    s->pending.push_back(ch);
+  } else {
+    uint32_t* dA = s->d_pts;
+    uint32_t* dB = s->d_pts + 16ull * np;
+    TRY(fold_points_launch(s->curve, dA, dA, x_inv, x, dB, dB, x, x_inv, 2, n));
+  }
   s->len = n;
   s->lr_done = false;
+  if (!s->frozen && !s->freeze_disabled && n > 1 && n <= s->freeze_cap) TRY(ipa_freeze(s));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return 0;
 }
 
@@ -935,6 +1029,7 @@ int bpgpu_ipa_export(bpgpu_ipa* s, uint64_t* a_gens_xyz, uint64_t* b_gens_xyz, u
   TRY(check_ready());
   if (!s) return fail(BPGPU_E_ARG, "null session");
   if (s->lr_done) return fail(BPGPU_E_STATE, "export between round_lr and round_fold");
+  if (a_gens_xyz || b_gens_xyz) TRY(ipa_materialise(s));
   const size_t n = s->len, np = s->np;
   hipStream_t st = g_ctx.stream;
   TRY(g_ctx.st_out.ensure(n * 96));

@@ -738,6 +738,89 @@ __global__ void __launch_bounds__(256) k_fold_scalars(uint32_t* __restrict__ v0,
 }
 
 // ---------------------------------------------------------------------------
+// Deferred generator folding for the short rounds of the prover.  Once the vectors are
+// short, one lane's 128-doubling ladder (a millisecond) costs more than an MSM over the generators
+// as they were when folding stopped ("frozen", n0 of each of A and B).  The current generator i
+// (vector length 2n) is then  A_i = sum_{j = i mod 2n} wA_j A0_j  with wA_j the product of the
+// challenges applied so far, so the round's L and R (bp_iter.rs:68-81) are MSMs over A0, B0 with
+// scalars a_{.} wA_j / b_{.} wB_j, half of them zero.  Only L, R are proof outputs, so the folded
+// generators are never needed (bpgpu_ipa_export replays the point folds if it is called).
+// Weights are kept in device form (value * 2^261), so montmul(ark scalar, weight) is an ark scalar.
+// ---------------------------------------------------------------------------
+template <int SF>
+__global__ void __launch_bounds__(256) k_frozen_init(uint32_t* __restrict__ w, uint32_t count) {
+  using F = Fp<SF>;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  uint32_t o[8];
+  F::store_packed(F::one(), o);
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[8ull * j + k] = o[k];
+}
+
+// after a fold with challenge x of vectors of length 2n:  A'_i = x^-1 A_i + x A_{i+n},  B'_i = x B_i + x^-1 B_{i+n}
+template <int SF>
+__global__ void __launch_bounds__(256) k_frozen_update(uint32_t* __restrict__ wA, uint32_t* __restrict__ wB, uint32_t n0,
+                                                       uint32_t n, FoldScalars xs /* lo = x, hi = x^-1 */) {
+  using F = Fp<SF>;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n0) return;
+  const bool low = (j & (2 * n - 1)) < n;
+  Fe x = F::load_ark(xs.lo), xi = F::load_ark(xs.hi);
+  uint32_t a[8], b[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    a[k] = wA[8ull * j + k];
+    b[k] = wB[8ull * j + k];
+  }
+  Fe na = F::mul(F::unpack(a), low ? xi : x), nb = F::mul(F::unpack(b), low ? x : xi);
+  F::store_packed(na, a);
+  F::store_packed(nb, b);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    wA[8ull * j + k] = a[k];
+    wB[8ull * j + k] = b[k];
+  }
+}
+
+// scalars of the round's two MSMs over the frozen generators; vectors a, b have length 2n.
+// out layout (ark form): [L over A0 | L over B0 | R over A0 | R over B0], n0 each.
+template <int SF>
+__global__ void __launch_bounds__(256) k_frozen_scalars(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                        const uint32_t* __restrict__ wA, const uint32_t* __restrict__ wB,
+                                                        uint32_t* __restrict__ out, uint32_t n0, uint32_t n) {
+  using F = Fp<SF>;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n0) return;
+  const uint32_t i = j & (2 * n - 1);
+  const bool low = i < n;
+  // L = msm(A[n..], a[..n]) + msm(B[..n], b[n..]);  R = msm(A[..n], a[n..]) + msm(B[n..], b[..n])
+  const uint32_t ia = low ? i + n : i - n, ib = ia;
+  uint32_t sa[8], sb[8], ua[8], ub[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    sa[k] = a[8ull * ia + k];
+    sb[k] = b[8ull * ib + k];
+    ua[k] = wA[8ull * j + k];
+    ub[k] = wB[8ull * j + k];
+  }
+  uint32_t pa[8], pb[8];
+  F::store_packed(F::mul(F::unpack(sa), F::unpack(ua)), pa);
+  F::store_packed(F::mul(F::unpack(sb), F::unpack(ub)), pb);
+  uint32_t* la = out + 8ull * j;
+  uint32_t* lb = out + 8ull * (n0 + j);
+  uint32_t* ra = out + 8ull * (2ull * n0 + j);
+  uint32_t* rb = out + 8ull * (3ull * n0 + j);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    la[k] = low ? 0u : pa[k];  // A_j with j mod 2n >= n pairs with a[i - n] in L
+    ra[k] = low ? pa[k] : 0u;  // A_j with j mod 2n <  n pairs with a[i + n] in R
+    lb[k] = low ? pb[k] : 0u;  // B_j with j mod 2n <  n pairs with b[i + n] in L
+    rb[k] = low ? 0u : pb[k];  // B_j with j mod 2n >= n pairs with b[i - n] in R
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Generator fold (base field BF = curve id):  out[i] = s_lo * g[i] + s_hi * g[i+n]
 // (bp_iter.rs:97-104).  Every lane uses the same two scalars, so they are recoded once on the
 // host and the whole grid follows one branch-uniform schedule:

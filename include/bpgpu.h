@@ -49,6 +49,9 @@ void bpgpu_shutdown(void);
 const char* bpgpu_last_error(void);
 /* MSM window width override for tuning (0 = automatic).  */
 int bpgpu_set_window_bits(int c);
+/* IPA sessions whose vectors are at most this long defer the generator fold ("deferred
+ * folding"; default 2^15, 0 = always fold).  Tuning only: results are identical either way. */
+int bpgpu_set_freeze_len(size_t len);
 
 /* ---- variable-base MSM ------------------------------------------------------
  * Replaces `pippenger_msm` (= `crate::util::msm`), reference src/util/msm.rs:88-193

@@ -223,3 +223,38 @@ def test_msm_full_size_properties(ffi):
     want = co.msm_pippenger(0, pts[:k], s[:k], threads=16)
     got = ffi.msm(0, pts[:k], s[:k])
     assert int(got[8]) == 0 and (got[:8] == want[:8]).all()
+
+
+@pytest.mark.parametrize("freeze", [0, 2, 8, 64, 1 << 15])
+def test_bp_prove_deferred_fold_equivalence(ffi, freeze):
+    """Deferring the generator fold (frozen generators + challenge-product weights) changes nothing:
+    same L, R, final scalars and exported generators for every freeze length, against the oracle."""
+    from oracle import c_oracle as co
+    c = pm.PALLAS
+    n = 64
+    A, B, q, a, b, seed = co.ipa_inputs(0, n)
+    ls, rs, ch, fa, fb = co.bp_prove(0, A, B, q, a, b, seed, threads=4)
+    ffi.set_freeze_len(freeze)
+    try:
+        sess = ffi.IpaSession(0, A, B, q, a, b)
+        k = 0
+        while len(sess) > 1:
+            l, r = sess.round_lr()
+            assert (l[:8] == ls[k][:8]).all() and (r[:8] == rs[k][:8]).all(), (freeze, k)
+            sess.round_fold(ch[k], co.scalar_inverse(0, ch[k]))
+            k += 1
+            if len(sess) == 4:
+                # export in the middle of a (possibly frozen) session: folded generators are materialised
+                gA, gB, ga, gb = sess.export()
+                wantA = A
+                wantB = B
+                for j in range(k):
+                    xi = co.scalar_inverse(0, ch[j])
+                    wantA = co.fold_points(0, wantA, xi, ch[j])
+                    wantB = co.fold_points(0, wantB, ch[j], xi)
+                assert (gA == wantA).all() and (gB == wantB).all(), freeze
+        ga, gb = sess.finish()
+        sess.free()
+        assert (ga == fa).all() and (gb == fb).all()
+    finally:
+        ffi.set_freeze_len(1 << 15)
