@@ -74,7 +74,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
   int window_bits = 0;
-  size_t freeze_len = 1u << 15;  // vectors this short defer the generator fold (0 = never)
+  size_t freeze_len = 1u << 16;  // vectors this short defer the generator fold (0 = never)
   int num_cus = 256;
   float msm_ms[8] = {};
   // MSM workspace (grow-only)

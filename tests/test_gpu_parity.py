@@ -257,4 +257,4 @@ def test_bp_prove_deferred_fold_equivalence(ffi, freeze):
         sess.free()
         assert (ga == fa).all() and (gb == fb).all()
     finally:
-        ffi.set_freeze_len(1 << 15)
+        ffi.set_freeze_len(1 << 16)

@@ -8,6 +8,8 @@ from bulletproofs_amd import ffi, ark_bp
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ffi.init(0)
+if len(sys.argv) > 2:
+    ffi.set_freeze_len(1 << int(sys.argv[2]))
 n = 1 << k
 t0 = time.perf_counter()
 pts = bench.synth_points(ffi, 0, 2 * n + 1, seed=5)
@@ -15,7 +17,7 @@ print("inputs", time.perf_counter() - t0, flush=True)
 A, B, q = pts[:n], pts[n:2 * n], pts[2 * n:]
 a, b = bench.synth_scalars(n, 6), bench.synth_scalars(n, 7)
 seed = bytes(range(32))
-for rep in range(3):
+for rep in range(4):
     t0 = time.perf_counter()
     pf = ark_bp.bp_prove(0, A, B, q, a, b, seed)
     print(f"N=2^{k} prove wall {1e3*(time.perf_counter()-t0):.1f} ms, inner {pf['prove_ms']:.1f} ms, rounds {len(pf['ls'])}", flush=True)

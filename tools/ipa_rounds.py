@@ -13,7 +13,7 @@ pts = bench.synth_points(ffi, 0, 2 * n + 1, seed=5)
 A, B, q = pts[:n], pts[n:2 * n], pts[2 * n:]
 a, b = bench.synth_scalars(n, 6), bench.synth_scalars(n, 7)
 for rep in range(2):
-    s = ffi.IpaSession(0, A, B, q, a, b)
+    t0 = time.perf_counter(); s = ffi.IpaSession(0, A, B, q, a, b); print('begin %.3f ms' % (1e3*(time.perf_counter()-t0)))
     x = bench.synth_scalars(1, 9)[0]
     xi = ark_bp.scalar_inverse(0, x)
     while len(s) > 1:
