@@ -144,8 +144,9 @@ int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t o
 /* ---- instrumentation ----------------------------------------------------------
  * Duration in milliseconds of the GPU phases of the last bpgpu_msm* call on this
  * thread's context, measured with HIP events on the library's stream:
- * [0] digits+histogram, [1] scan, [2] scatter, [3] bucket accumulate, [4] fix-up,
- * [5] bucket reduce, [6] host tail (wall), [7] total GPU. */
+ * [0] digits + coarse histogram, [1] bin scan + scatter to bins, [2] sort inside bins,
+ * [3] bucket accumulation (k_accum + k_heavy_merge), [4] unused, [5] bucket reduction,
+ * [6] host tail (wall), [7] total GPU. */
 int bpgpu_last_msm_timings(float out_ms[8]);
 /* Sustained v_mad_u64_u32 issue rate (lane-ops/s) measured by a register-only loop:
  * the integer roofline bench.py prices the MSM against. */
