@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=20, help="log2 of the CPU-baseline sample size")
     ap.add_argument("--ipa-log2n", type=int, default=20, help="log2 N of the secondary IPA-prove measurement (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + --one-device rehearses N > 1 ranks on a single GPU")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -87,13 +90,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
+    dev_index = 0 if args.one_device else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     from bulletproofs_amd import ffi
-    ffi.init(local_rank)
+    ffi.init(dev_index)
     if args.window:
         ffi.set_window_bits(args.window)
     curve = 0 if args.curve == "pallas" else 1
@@ -105,7 +112,7 @@ def main():
     d_sc = ffi.scalars_to_device(sc)
 
     from bulletproofs_amd import sharded
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index) if args.backend == "nccl" else None
 
     def step():
         part = ffi.msm_device(curve, d_pts, d_sc, n)
@@ -127,7 +134,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     phase /= max(1, args.steps)
