@@ -89,7 +89,7 @@ struct Ec {
     Fe S = F::mul(p.x, V);
     Fe M = F::carry(F::mul_small(F::sqr(p.x), 3));
     Fe X3 = F::carry(F::sub(F::sub(F::sqr(M), S), S));
-    Fe Y3 = F::carry(F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y)));
+    Fe Y3 = F::mul_sub2(M, F::sub(S, X3), W, p.y);
     r.x = X3;
     r.y = Y3;
     r.zz = V;
@@ -108,7 +108,7 @@ struct Ec {
     Fe S = F::mul(p.x, V);
     Fe M = F::carry(F::mul_small(F::sqr(p.x), 3));
     Fe X3 = F::carry(F::sub(F::sub(F::sqr(M), S), S));
-    Fe Y3 = F::carry(F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y)));
+    Fe Y3 = F::mul_sub2(M, F::sub(S, X3), W, p.y);
     r.x = X3;
     r.y = Y3;
     r.zz = F::mul(V, p.zz);
@@ -140,7 +140,7 @@ struct Ec {
     Fe PPP = F::mul(P, PP);
     Fe Q = F::mul(acc.x, PP);
     Fe X3 = F::carry(F::sub(F::sub(F::sub(F::sqr(R), PPP), Q), Q));
-    Fe Y3 = F::carry(F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP)));
+    Fe Y3 = F::mul_sub2(R, F::sub(Q, X3), acc.y, PPP);
     acc.x = X3;
     acc.y = Y3;
     acc.zz = F::mul(acc.zz, PP);
@@ -166,7 +166,7 @@ struct Ec {
     Fe PPP = F::mul(P, PP);
     Fe Q = F::mul(U1, PP);
     Fe X3 = F::carry(F::sub(F::sub(F::sub(F::sqr(R), PPP), Q), Q));
-    Fe Y3 = F::carry(F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP)));
+    Fe Y3 = F::mul_sub2(R, F::sub(Q, X3), S1, PPP);
     r.x = X3;
     r.y = Y3;
     r.zz = F::mul(F::mul(a.zz, b.zz), PP);
