@@ -133,23 +133,36 @@ struct Fp {
     return r;
   }
 
-  // Montgomery reduction of 17 product columns t[0..16] (t[17] = 0 on entry)
+  // Montgomery reduction of 17 product columns t[0..16] (t[17] = 0 on entry).
+  // p == 1 (mod 2^29), so column k is cleared by SUBTRACTING m p 2^(29k) with m = t[k] mod 2^29
+  // (the plain low bits: one v_and).  t[k] - m is a multiple of 2^29 and (t[k] - m) >> 29 ==
+  // t[k] >> 29 (arithmetic shift), so the cleared column itself is never written: the carry is a
+  // shift and an add.  The result lies in (T/2^261 - p, T/2^261]: it may be negative, which the
+  // signed top limb carries.
   static BP_HD Fe redc(acc_t (&t)[18]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep 2^22 opaque so that m * 2^22 stays one multiply-add instead of a 64-bit shift and a
+    // 64-bit subtract (three instructions)
+    int32_t n8;
+    asm("s_mov_b32 %0, 0xffc00000" : "=s"(n8));  // -2^22
+#else
+    const int32_t n8 = -(int32_t)C::P29[8];
+#endif
+    const int64_t n1 = -(int64_t)C::P29[1], n2 = -(int64_t)C::P29[2], n3 = -(int64_t)C::P29[3], n4 = -(int64_t)C::P29[4];
     BP_UNROLL
     for (int k = 0; k < 9; k++) {
-      uint32_t m = (0u - (uint32_t)t[k]) & MASK29;  // p == 1 (mod 2^29)  =>  -p^-1 == -1
-      t[k] += (acc_t)m;
-      t[k + 1] += (acc_t)(int64_t)m * (int64_t)C::P29[1];
-      t[k + 2] += (acc_t)(int64_t)m * (int64_t)C::P29[2];
-      t[k + 3] += (acc_t)(int64_t)m * (int64_t)C::P29[3];
-      t[k + 4] += (acc_t)(int64_t)m * (int64_t)C::P29[4];
-      t[k + 8] += (acc_t)((int64_t)m << 22);
+      const int64_t m = (int64_t)((uint32_t)t[k] & MASK29);
+      t[k + 1] += (acc_t)(m * n1);
+      t[k + 2] += (acc_t)(m * n2);
+      t[k + 3] += (acc_t)(m * n3);
+      t[k + 4] += (acc_t)(m * n4);
+      t[k + 8] += (acc_t)(m * (int64_t)n8);
       bp_check_acc(t[k + 1]);
       bp_check_acc(t[k + 2]);
       bp_check_acc(t[k + 3]);
       bp_check_acc(t[k + 4]);
       bp_check_acc(t[k + 8]);
-      t[k + 1] += t[k] >> 29;  // exact: low 29 bits of t[k] are zero
+      t[k + 1] += t[k] >> 29;
       bp_check_acc(t[k + 1]);
     }
     Fe r;
