@@ -183,6 +183,8 @@ def main():
             "host_to_host": {"ms": h2h * 1e3, "points_per_s": n / h2h,
                              "note": "host buffers in, PCIe + Jacobian->affine conversion included (msm_bench.rs:45-48 window)"},
         }
+        if world == 1:
+            out["roofline_hbm"] = scalar_kernels_leg(ffi, curve)
         if world == 1 and args.ipa_log2n:
             out["ipa_prove"] = ipa_prove_leg(ffi, curve, args.ipa_log2n)
         if world == 1 and not args.no_cpu_baseline:
@@ -191,6 +193,37 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scalar_kernels_leg(ffi, curve, log2n=24):
+    """HBM roofline of the two streaming kernels of the fold (north-star: "HBM GB/s for scalar folding"):
+    k_fold_scalars (a' = x a_lo + x^-1 a_hi, bp_iter.rs:88-95: 64 B read + 32 B written per output) and
+    k_ip_partial (<a, b>, util/mod.rs:17-23: 64 B read per term), on vectors far larger than the 256 MiB
+    Infinity Cache, timed with HIP events on the library's stream."""
+    n = 1 << log2n
+    v = synth_scalars(2 * n, 91)
+    d_v = ffi.scalars_to_device(v)
+    d_o = ffi.DeviceBuffer(n * 32)
+    x, xi = synth_scalars(1, 92)[0], synth_scalars(1, 93)[0]
+    best_fold, best_ip = 1e9, 1e9
+    for _ in range(5):
+        ffi.fold_scalars_device(curve, d_v, n, x, xi, d_o)
+        best_fold = min(best_fold, ffi.last_op_ms())
+    d_b = ffi.DeviceBuffer(n * 32)
+    d_b.upload(v[n:])
+    for _ in range(5):
+        ffi.ip_device(curve, d_o, d_b, n)
+        best_ip = min(best_ip, ffi.last_op_ms())
+    for b in (d_v, d_o, d_b):
+        b.free()
+    peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md); about 6300 GB/s is achievable
+    fold_gbs = n * 96 / (best_fold * 1e-3) / 1e9
+    ip_gbs = n * 64 / (best_ip * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_fold_scalars", "achieved": fold_gbs, "peak": peak, "unit": "GB/s",
+            "frac": fold_gbs / peak, "traffic": None, "avg_kernel_ms": best_fold,
+            "outputs": n, "algorithmic_bytes_per_output": 96,
+            "k_ip": {"achieved": ip_gbs, "frac": ip_gbs / peak, "kernel_ms": best_ip, "terms": n,
+                     "algorithmic_bytes_per_term": 64}}
 
 
 def ipa_prove_leg(ffi, curve, log2n):

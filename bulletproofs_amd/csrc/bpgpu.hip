@@ -73,6 +73,7 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
+  hipEvent_t op_ev[2] = {};  // around the last ip / fold launch (bpgpu_last_op_ms)
   int window_bits = 0;
   size_t freeze_len = 1u << 16;  // vectors this short defer the generator fold (0 = never)
   int num_cus = 256;
@@ -338,13 +339,15 @@ int ip_launch(int curve, const uint32_t* d_sc, IpPair p0, IpPair p1, int npairs,
   if (nblk > 1024) nblk = 1024;
   TRY(C.st_ip.ensure((size_t)2 * nblk * 32));
   dim3 grid(nblk, npairs);
+  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
   if (curve == BPGPU_PALLAS) {
     k_ip_partial<1><<<grid, 256, 0, C.stream>>>(d_sc, p0, p1, n, C.st_ip.as<uint32_t>());
-    k_ip_final<1><<<npairs, 64, 0, C.stream>>>(C.st_ip.as<uint32_t>(), nblk, d_out0, d_out1);
+    k_ip_final<1><<<npairs, 256, 0, C.stream>>>(C.st_ip.as<uint32_t>(), nblk, d_out0, d_out1);
   } else {
     k_ip_partial<0><<<grid, 256, 0, C.stream>>>(d_sc, p0, p1, n, C.st_ip.as<uint32_t>());
-    k_ip_final<0><<<npairs, 64, 0, C.stream>>>(C.st_ip.as<uint32_t>(), nblk, d_out0, d_out1);
+    k_ip_final<0><<<npairs, 256, 0, C.stream>>>(C.st_ip.as<uint32_t>(), nblk, d_out0, d_out1);
   }
+  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -359,11 +362,16 @@ FoldScalars make_fold_scalars(const uint64_t lo[4], const uint64_t hi[4]) {
 int fold_scalars_launch(int curve, uint32_t* v0, uint32_t* o0, const FoldScalars& s0, uint32_t* v1, uint32_t* o1,
                         const FoldScalars& s1, int nvec, uint32_t n) {
   if (n == 0) return 0;
-  dim3 grid(cdiv(n, 256), nvec);
+  uint32_t gx = cdiv(n, 256);
+  const uint32_t cap = (uint32_t)g_ctx.num_cus * 16;
+  if (gx > cap) gx = cap;
+  dim3 grid(gx, nvec);
+  HIP_TRY(hipEventRecord(g_ctx.op_ev[0], g_ctx.stream));
   if (curve == BPGPU_PALLAS)
     k_fold_scalars<1><<<grid, 256, 0, g_ctx.stream>>>(v0, o0, s0, v1, o1, s1, n);
   else
     k_fold_scalars<0><<<grid, 256, 0, g_ctx.stream>>>(v0, o0, s0, v1, o1, s1, n);
+  HIP_TRY(hipEventRecord(g_ctx.op_ev[1], g_ctx.stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -517,10 +525,12 @@ int fold_points_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64
   HIP_TRY(hipMemcpyAsync(C.fold_plans.p, plans, sizeof plans, hipMemcpyHostToDevice, C.stream));
   HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
   dim3 grid(cdiv(n, 64), nvec);
+  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
   if (curve == BPGPU_PALLAS)
     k_fold_points<0><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<FoldPlan>(), n);
   else
     k_fold_points<1><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<FoldPlan>(), n);
+  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -603,6 +613,7 @@ int bpgpu_init(int device) {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
   for (auto& e : g_ctx.ev) HIP_TRY(hipEventCreate(&e));
+  for (auto& e : g_ctx.op_ev) HIP_TRY(hipEventCreate(&e));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   g_ctx.num_cus = prop.multiProcessorCount;
@@ -620,6 +631,7 @@ void bpgpu_shutdown(void) {
                     &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip, &g_ctx.fold_plans})
     b->release();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);
+  for (auto& e : g_ctx.op_ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.ready = false;
 }
@@ -1087,6 +1099,15 @@ int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t o
 int bpgpu_last_msm_timings(float out_ms[8]) {
   if (!out_ms) return fail(BPGPU_E_ARG, "null pointer");
   memcpy(out_ms, g_ctx.msm_ms, sizeof g_ctx.msm_ms);
+  return 0;
+}
+
+int bpgpu_last_op_ms(float* ms) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  if (!ms) return fail(BPGPU_E_ARG, "null pointer");
+  HIP_TRY(hipEventSynchronize(g_ctx.op_ev[1]));
+  HIP_TRY(hipEventElapsedTime(ms, g_ctx.op_ev[0], g_ctx.op_ev[1]));
   return 0;
 }
 

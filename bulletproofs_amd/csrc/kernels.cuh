@@ -652,12 +652,11 @@ __global__ void __launch_bounds__(256) k_ip_partial(const uint32_t* __restrict__
   uint32_t tid = threadIdx.x;
   Fe acc = F::zero();
   for (uint32_t i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
-    uint32_t wa[8], wb[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      wa[k] = a[8ull * i + k];
-      wb[k] = b[8ull * i + k];
-    }
+    const uint4* pa = reinterpret_cast<const uint4*>(a + 8ull * i);
+    const uint4* pb = reinterpret_cast<const uint4*>(b + 8ull * i);
+    uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+    uint32_t wa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    uint32_t wb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     // (a 2^256)(b 2^256)/2^261 = ab 2^251
     Fe pdt = F::mul(F::unpack(wa), F::unpack(wb));
     acc = fe_partial_reduce<SF>(F::add(acc, pdt));
@@ -684,26 +683,42 @@ __global__ void __launch_bounds__(256) k_ip_partial(const uint32_t* __restrict__
   }
 }
 
-// out[y] = (sum_x partial[y][x]) * 2^5   i.e. ab 2^251 -> ab 2^256 (ark form)
+// out[y] = (sum_x partial[y][x]) * 2^5   i.e. ab 2^251 -> ab 2^256 (ark form); one workgroup per pair
 template <int SF>
-__global__ void __launch_bounds__(64) k_ip_final(const uint32_t* __restrict__ partial, uint32_t nparts,
-                                                 uint32_t* __restrict__ out0, uint32_t* __restrict__ out1) {
+__global__ void __launch_bounds__(256) k_ip_final(const uint32_t* __restrict__ partial, uint32_t nparts,
+                                                  uint32_t* __restrict__ out0, uint32_t* __restrict__ out1) {
   using F = Fp<SF>;
-  if (threadIdx.x != 0) return;
+  __shared__ int32_t sh[256 * 9];
+  const uint32_t tid = threadIdx.x;
   Fe acc = F::zero();
-  for (uint32_t i = 0; i < nparts; i++) {
-    uint32_t w[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = partial[8ull * (blockIdx.x * nparts + i) + k];
+  for (uint32_t i = tid; i < nparts; i += 256) {
+    const uint4* pp = reinterpret_cast<const uint4*>(partial + 8ull * (blockIdx.x * nparts + i));
+    uint4 p0 = pp[0], p1 = pp[1];
+    uint32_t w[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
     acc = fe_partial_reduce<SF>(F::add(acc, F::unpack(w)));
   }
-  // montmul(x 2^251, 2^266) = x 2^256
-  Fe r = F::mul(acc, F::from_const(F::C::C256TO261));
-  uint32_t w[8];
-  F::store_packed(r, w);
-  uint32_t* o = blockIdx.x == 0 ? out0 : out1;
 #pragma unroll
-  for (int k = 0; k < 8; k++) o[k] = w[k];
+  for (int k = 0; k < 9; k++) sh[k * 256 + tid] = acc.l[k];
+  for (uint32_t d = 128; d >= 1; d >>= 1) {
+    __syncthreads();
+    if (tid < d) {
+      Fe o;
+#pragma unroll
+      for (int k = 0; k < 9; k++) o.l[k] = sh[k * 256 + tid + d];
+      acc = fe_partial_reduce<SF>(F::add(acc, o));
+#pragma unroll
+      for (int k = 0; k < 9; k++) sh[k * 256 + tid] = acc.l[k];
+    }
+  }
+  if (tid == 0) {
+    // montmul(x 2^251, 2^266) = x 2^256
+    Fe r = F::mul(acc, F::from_const(F::C::C256TO261));
+    uint32_t w[8];
+    F::store_packed(r, w);
+    uint32_t* o = blockIdx.x == 0 ? out0 : out1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k] = w[k];
+  }
 }
 
 struct FoldScalars {
@@ -717,24 +732,31 @@ __global__ void __launch_bounds__(256) k_fold_scalars(uint32_t* __restrict__ v0,
                                                       FoldScalars s0, uint32_t* __restrict__ v1,
                                                       uint32_t* __restrict__ o1, FoldScalars s1, uint32_t n) {
   using F = Fp<SF>;
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
   const uint32_t* v = blockIdx.y == 0 ? v0 : v1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
-  const FoldScalars& s = blockIdx.y == 0 ? s0 : s1;
-  // device form of the two multipliers: montmul(v 2^256, s 2^261) = vs 2^256, ark form again
-  Fe slo = F::load_ark(s.lo), shi = F::load_ark(s.hi);
-  uint32_t wl[8], wh[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    wl[k] = v[8ull * i + k];
-    wh[k] = v[8ull * (i + n) + k];
+  // device form of the two multipliers, once per lane: montmul(v 2^256, s 2^261) = vs 2^256, ark form again
+  Fe slo, shi;
+  if (blockIdx.y == 0) {
+    slo = F::load_ark(s0.lo);
+    shi = F::load_ark(s0.hi);
+  } else {
+    slo = F::load_ark(s1.lo);
+    shi = F::load_ark(s1.hi);
   }
-  Fe r = F::add(F::mul(F::unpack(wl), slo), F::mul(F::unpack(wh), shi));
-  uint32_t w[8];
-  F::store_packed(r, w);
-#pragma unroll
-  for (int k = 0; k < 8; k++) o[8ull * i + k] = w[k];
+  // `o` may alias `v`: every output reads only its own two inputs before it is written
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint4* pl = reinterpret_cast<const uint4*>(v + 8ull * i);
+    const uint4* ph = reinterpret_cast<const uint4*>(v + 8ull * (i + n));
+    uint4 l0 = pl[0], l1 = pl[1], h0 = ph[0], h1 = ph[1];
+    uint32_t wl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    uint32_t wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    Fe r = F::add(F::mul(F::unpack(wl), slo), F::mul(F::unpack(wh), shi));
+    uint32_t w[8];
+    F::store_packed(r, w);
+    uint4* po = reinterpret_cast<uint4*>(o + 8ull * i);
+    po[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    po[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
 }
 
 // ---------------------------------------------------------------------------

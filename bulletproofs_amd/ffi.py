@@ -48,6 +48,7 @@ SIGNATURES = {
     "bpgpu_ipa_free": (None, [c_void_p]),
     "bpgpu_points_sum": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
     "bpgpu_last_msm_timings": (c_int, [POINTER(c_float)]),
+    "bpgpu_last_op_ms": (c_int, [POINTER(c_float)]),
     "bpgpu_measure_mad_peak": (c_int, [POINTER(c_double)]),
 }
 
@@ -251,6 +252,12 @@ def last_msm_timings():
     out = (c_float * 8)()
     _check(load().bpgpu_last_msm_timings(out))
     return list(out)
+
+
+def last_op_ms():
+    v = c_float()
+    _check(load().bpgpu_last_op_ms(ctypes.byref(v)))
+    return v.value
 
 
 def measure_mad_peak():

@@ -10,6 +10,8 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ffi.init(0)
 if len(sys.argv) > 2:
     ffi.set_freeze_len(1 << int(sys.argv[2]))
+if len(sys.argv) > 3:
+    ffi.set_window_bits(int(sys.argv[3]))
 n = 1 << k
 t0 = time.perf_counter()
 pts = bench.synth_points(ffi, 0, 2 * n + 1, seed=5)
