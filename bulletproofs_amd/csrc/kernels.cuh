@@ -322,12 +322,18 @@ __global__ void __launch_bounds__(1024) k_bin_offsets(SortPlan sp, const uint32_
   }
 }
 
+// The tile's entries are first grouped by bucket in LDS and then written out in index order, so
+// that a wave's stores cover a few contiguous runs instead of 64 scattered words (scattered 4-byte
+// stores cost a 32-byte memory write each: WRITE_SIZE was 6x the algorithmic bytes).
 __global__ void __launch_bounds__(1024) k_bin_place(SortPlan sp, const uint32_t* __restrict__ bin_start,
                                                     const uint32_t* __restrict__ tile_start,
                                                     const uint32_t* __restrict__ ent_idx,
                                                     const uint16_t* __restrict__ ent_fine, const uint32_t* __restrict__ offs,
                                                     uint32_t* __restrict__ bcursor, uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t cnt[1024];
+  __shared__ uint32_t cnt[1024];    // counts, then cursors into buf
+  __shared__ uint32_t gdst[1024];   // scan scratch, then (global position - LDS position) of each bucket's run
+  __shared__ uint32_t buf[BIN_TILE];
+  __shared__ uint16_t bfine[BIN_TILE];
   const uint32_t tid = threadIdx.x, F = 1u << sp.fine_bits;
   uint32_t bin, lo, hi;
   if (!tile_lookup(tile_start, bin_start, sp.nbins, blockIdx.x, bin, lo, hi)) return;
@@ -335,17 +341,34 @@ __global__ void __launch_bounds__(1024) k_bin_place(SortPlan sp, const uint32_t*
   __syncthreads();
   for (uint32_t e = lo + tid; e < hi; e += 1024) atomicAdd(&cnt[ent_fine[e]], 1u);
   __syncthreads();
-  uint32_t v = cnt[tid];
+  const uint32_t v = cnt[tid];
+  gdst[tid] = v;
   __syncthreads();
-  if (tid < F) {
-    uint64_t bkt = (uint64_t)bin * F + tid;
-    cnt[tid] = offs[bkt] + (v ? atomicAdd(&bcursor[bkt], v) : 0u);  // this tile's slice of the bucket
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t t = tid >= d ? gdst[tid - d] : 0;
+    __syncthreads();
+    gdst[tid] += t;
+    __syncthreads();
   }
+  const uint32_t loff = gdst[tid] - v;  // first LDS slot of this bucket's run
+  __syncthreads();
+  uint32_t g = 0;
+  if (tid < F && v) {
+    uint64_t bkt = (uint64_t)bin * F + tid;
+    g = offs[bkt] + atomicAdd(&bcursor[bkt], v);  // this tile's slice of the bucket
+  }
+  gdst[tid] = g - loff;
+  cnt[tid] = loff;
   __syncthreads();
   for (uint32_t e = lo + tid; e < hi; e += 1024) {
-    uint32_t pos = atomicAdd(&cnt[ent_fine[e]], 1u);
-    sorted[pos] = ent_idx[e];
+    uint32_t f = ent_fine[e];
+    uint32_t p = atomicAdd(&cnt[f], 1u);
+    buf[p] = ent_idx[e];
+    bfine[p] = (uint16_t)f;
   }
+  __syncthreads();
+  const uint32_t cntn = hi - lo;
+  for (uint32_t p = tid; p < cntn; p += 1024) sorted[gdst[bfine[p]] + p] = buf[p];
 }
 
 // sum over the first 2*FIRST lanes of a wave, result valid in lane 0
