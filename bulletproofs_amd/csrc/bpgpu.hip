@@ -206,7 +206,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   sp.nbins = NB >> sp.fine_bits;
   sp.tiles = cdiv(slots, 1024);
   const uint32_t part_grid = sp.tiles < 512 ? sp.tiles : 512;
-  const size_t lds_bytes = (size_t)sp.nbins * 8;
+  const size_t lds_bytes = (size_t)sp.nbins * 4;
   if (lds_bytes > 64 * 1024) return fail(BPGPU_E_ARG, "window width %d needs %zu B of LDS bin counters", c, lds_bytes);
 
   TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2 + 64));  // bin_count | chunk counter | bin_cursor
@@ -214,7 +214,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   TRY(C.bcount.ensure((size_t)NB * 4));
   TRY(C.offs.ensure((size_t)(NB + 1) * 4));
   TRY(C.order.ensure((size_t)NB * 4));
-  TRY(C.canon.ensure((size_t)slots * 32));
+  TRY(C.canon.ensure((size_t)slots * W * 4));  // window-major digit words
   TRY(C.ent_idx.ensure((size_t)slots * W * 4 + 4));
   TRY(C.ent_fine.ensure((size_t)slots * W * 2 + 4));
   TRY(C.sorted.ensure((size_t)slots * W * 4 + 4));
@@ -249,8 +249,8 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   k_part_count<SF><<<part_grid, 1024, lds_bytes, st>>>(plan, sp, d_scalars, C.canon.as<uint32_t>(), bin_count);
   HIP_TRY(hipEventRecord(C.ev[1], st));
   k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, tile_start, bin_cursor, sp.nbins);
-  k_part_scatter<<<part_grid, 1024, lds_bytes, st>>>(plan, sp, C.canon.as<uint32_t>(), bin_start, bin_cursor,
-                                                     C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>());
+  k_part_scatter<<<dim3(cdiv(plan.n, PART_TILE), plan.M * W), 1024, 0, st>>>(
+      plan, sp, C.canon.as<uint32_t>(), bin_start, bin_cursor, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>());
   HIP_TRY(hipEventRecord(C.ev[2], st));
   HIP_TRY(hipMemsetAsync(C.bcount.p, 0, (size_t)NB * 4, st));
   k_bin_count<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_fine.as<uint16_t>(), C.bcount.as<uint32_t>());

@@ -46,9 +46,9 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t (&w)[8], int pos
 // atomics are one per (workgroup, coarse bin).
 //   bucket id  = (m*W + j) << (c-1) | (|digit| - 1)              (global, over all windows)
 //   coarse bin = bucket id >> fine_bits,  fine = bucket id & (2^fine_bits - 1)
-//   k_part_count    digits -> per-workgroup LDS histogram of coarse bins -> bin_count
+//   k_part_count    digits (kept, window-major) -> per-workgroup LDS histogram of coarse bins -> bin_count
 //   k_bin_scan      exclusive scan of the bin counts (one small workgroup)
-//   k_part_scatter  digits again -> (index|sign, fine) entries appended to their bin
+//   k_part_scatter  digit words -> (index|sign, fine) entries, grouped by bin in LDS, appended to their bin
 //   k_bin_count / k_bin_offsets / k_bin_place   counting sort of each bin by fine bucket -> sorted[], offs[]
 // ---------------------------------------------------------------------------
 constexpr uint32_t HEAVY_T_MIN = 128;   // a single lane never walks a list longer than max(this, 4 x the mean)
@@ -86,43 +86,40 @@ __device__ __forceinline__ bool slot_lookup(const MsmPlan& plan, uint64_t gid, i
   return true;
 }
 
-// calls f(bucket_id, neg) for every non-zero signed digit of the canonical scalar w
-template <class Fn>
-__device__ __forceinline__ void for_each_digit(const uint32_t (&w)[8], int m, int W, int c, Fn f) {
-  const uint32_t half = 1u << (c - 1);
-  uint32_t carry = 0;
-  for (int j = 0; j < W; j++) {
-    uint32_t bits = extract_bits(w, j * c, c) + carry;
-    uint32_t neg = bits > half ? 1u : 0u;
-    uint32_t mag = neg ? (1u << c) - bits : bits;
-    carry = neg;
-    if (mag != 0) f(((uint32_t)(m * W + j) << (c - 1)) + (mag - 1), neg);
-  }
-}
-
-// SF = scalar field id.  Also stores the canonical scalars (into_repr, msm.rs:96) for the scatter pass.
+// digit word of a (slot, window): |digit| | sign << 31; 0 = zero digit, no entry
+// SF = scalar field id.  Canonical scalar (into_repr, msm.rs:96) -> signed digits, stored window-major
+// (dig[(m*W + j)*n + t]) for the scatter pass, and counted into the coarse-bin histogram.
 template <int SF>
 __global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, const uint32_t* __restrict__ scalars,
-                                                     uint32_t* __restrict__ canon, uint32_t* __restrict__ bin_count) {
+                                                     uint32_t* __restrict__ dig, uint32_t* __restrict__ bin_count) {
   using F = Fp<SF>;
   extern __shared__ uint32_t lds[];
   uint32_t* cnt = lds;
   for (uint32_t b = threadIdx.x; b < sp.nbins; b += 1024) cnt[b] = 0;
   __syncthreads();
+  const int c = plan.c, W = plan.W;
+  const uint32_t half = 1u << (c - 1);
   for (uint32_t tile = blockIdx.x; tile < sp.tiles; tile += gridDim.x) {
     uint64_t gid = (uint64_t)tile * 1024 + threadIdx.x;
     int m;
     uint32_t pt_idx, sc_idx;
     if (!slot_lookup(plan, gid, m, pt_idx, sc_idx)) continue;
+    const uint32_t t = (uint32_t)(gid - (uint64_t)m * plan.n);
     const uint4* sp4 = reinterpret_cast<const uint4*>(scalars + 8ull * sc_idx);
     uint4 lo = sp4[0], hi = sp4[1];
     uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     Fe v = F::mul(F::unpack(w), F::from_const(F::C::C256TOCANON));
     F::pack(F::canon(v), w);
-    uint4* cp = reinterpret_cast<uint4*>(canon + 8ull * gid);
-    cp[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    cp[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    for_each_digit(w, m, plan.W, plan.c, [&](uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> sp.fine_bits], 1u); });
+    uint32_t carry = 0;
+    uint32_t* dp = dig + (uint64_t)m * W * plan.n + t;
+    for (int j = 0; j < W; j++) {
+      uint32_t bits = extract_bits(w, j * c, c) + carry;
+      uint32_t neg = bits > half ? 1u : 0u;
+      uint32_t mag = neg ? (1u << c) - bits : bits;
+      carry = neg;
+      dp[(uint64_t)j * plan.n] = mag | (neg << 31);
+      if (mag) atomicAdd(&cnt[(((uint32_t)(m * W + j) << (c - 1)) + (mag - 1)) >> sp.fine_bits], 1u);
+    }
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < sp.nbins; b += 1024) {
@@ -174,48 +171,77 @@ __global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t* __restrict__ 
   }
 }
 
-__global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp, const uint32_t* __restrict__ canon,
+// One workgroup takes PART_TILE slots of ONE window: its entries fall into that window's
+// 2^(c-1-fine_bits) <= 1024 coarse bins only, so they can be grouped by bin in LDS and leave as
+// contiguous runs (a tile of all windows at once would spread over every bin, a few entries each,
+// and every 4-byte store would cost a 32-byte memory write).
+constexpr uint32_t PART_TILE = 8192;
+__global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp, const uint32_t* __restrict__ dig,
                                                        const uint32_t* __restrict__ bin_start,
                                                        uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ ent_idx,
                                                        uint16_t* __restrict__ ent_fine) {
-  extern __shared__ uint32_t lds[];
-  uint32_t* cnt = lds;
-  uint32_t* cur = lds + sp.nbins;
+  __shared__ uint32_t cnt[1024];   // counts, then cursors into buf
+  __shared__ uint32_t gdst[1024];  // scan scratch, then (global position - LDS position) of each bin's run
+  __shared__ uint32_t buf[PART_TILE];
+  __shared__ uint16_t bfine[PART_TILE];
+  __shared__ uint16_t bbin[PART_TILE];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wj = blockIdx.y;  // m*W + j
+  const int m = (int)(wj / (uint32_t)plan.W);
+  const uint32_t nbw = 1u << (plan.c - 1 - sp.fine_bits);  // coarse bins per window
   const uint32_t fine_mask = (1u << sp.fine_bits) - 1u;
-  for (uint32_t b = threadIdx.x; b < sp.nbins; b += 1024) cnt[b] = 0;
+  const uint32_t t0 = blockIdx.x * PART_TILE;
+  const uint32_t t1 = t0 + PART_TILE < plan.n ? t0 + PART_TILE : plan.n;
+  const uint32_t* dw = dig + (uint64_t)wj * plan.n;
+  cnt[tid] = 0;
   __syncthreads();
-  // sweep A: this workgroup's bin counts
-  for (uint32_t tile = blockIdx.x; tile < sp.tiles; tile += gridDim.x) {
-    uint64_t gid = (uint64_t)tile * 1024 + threadIdx.x;
-    int m;
-    uint32_t pt_idx, sc_idx;
-    if (!slot_lookup(plan, gid, m, pt_idx, sc_idx)) continue;
-    const uint4* cp = reinterpret_cast<const uint4*>(canon + 8ull * gid);
-    uint4 lo = cp[0], hi = cp[1];
-    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    for_each_digit(w, m, plan.W, plan.c, [&](uint32_t bucket, uint32_t) { atomicAdd(&cnt[bucket >> sp.fine_bits], 1u); });
+  for (uint32_t t = t0 + tid; t < t1; t += 1024) {
+    uint32_t d = dw[t] & 0x7fffffffu;
+    if (d) atomicAdd(&cnt[(d - 1) >> sp.fine_bits], 1u);
   }
   __syncthreads();
-  // reserve this workgroup's slice of every bin
-  for (uint32_t b = threadIdx.x; b < sp.nbins; b += 1024) {
-    uint32_t v = cnt[b];
-    cur[b] = bin_start[b] + (v ? atomicAdd(&bin_cursor[(uint64_t)b * BIN_PAD], v) : 0u);
+  const uint32_t v = cnt[tid];
+  gdst[tid] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t x = tid >= d ? gdst[tid - d] : 0;
+    __syncthreads();
+    gdst[tid] += x;
+    __syncthreads();
+  }
+  const uint32_t total = gdst[1023];
+  const uint32_t loff = gdst[tid] - v;
+  __syncthreads();
+  uint32_t g = 0;
+  if (tid < nbw && v) {
+    uint32_t b = wj * nbw + tid;
+    g = bin_start[b] + atomicAdd(&bin_cursor[(uint64_t)b * BIN_PAD], v);
+  }
+  gdst[tid] = g - loff;
+  cnt[tid] = loff;
+  __syncthreads();
+  // segment of the first slot; slots advance through at most 3 segments
+  for (uint32_t t = t0 + tid; t < t1; t += 1024) {
+    uint32_t dv = dw[t];
+    uint32_t d = dv & 0x7fffffffu;
+    if (!d) continue;
+    uint32_t r = t;
+    int s = 0;
+    while (s < 2 && r >= plan.seg[m][s].count) {
+      r -= plan.seg[m][s].count;
+      s++;
+    }
+    uint32_t lb = (d - 1) >> sp.fine_bits;
+    uint32_t p = atomicAdd(&cnt[lb], 1u);
+    buf[p] = (plan.seg[m][s].pt_off + r) | (dv & 0x80000000u);
+    bfine[p] = (uint16_t)((d - 1) & fine_mask);
+    bbin[p] = (uint16_t)lb;
   }
   __syncthreads();
-  // sweep B: append the entries
-  for (uint32_t tile = blockIdx.x; tile < sp.tiles; tile += gridDim.x) {
-    uint64_t gid = (uint64_t)tile * 1024 + threadIdx.x;
-    int m;
-    uint32_t pt_idx, sc_idx;
-    if (!slot_lookup(plan, gid, m, pt_idx, sc_idx)) continue;
-    const uint4* cp = reinterpret_cast<const uint4*>(canon + 8ull * gid);
-    uint4 lo = cp[0], hi = cp[1];
-    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    for_each_digit(w, m, plan.W, plan.c, [&](uint32_t bucket, uint32_t neg) {
-      uint32_t pos = atomicAdd(&cur[bucket >> sp.fine_bits], 1u);
-      ent_idx[pos] = pt_idx | (neg << 31);
-      ent_fine[pos] = (uint16_t)(bucket & fine_mask);
-    });
+  for (uint32_t p = tid; p < total; p += 1024) {
+    uint32_t pos = gdst[bbin[p]] + p;
+    ent_idx[pos] = buf[p];
+    ent_fine[pos] = bfine[p];
   }
 }
 
