@@ -535,6 +535,132 @@ int fold_points_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64
   return 0;
 }
 
+// ---- monic fold: Eisenstein-unit expansion of s = k1 + k2 lambda ------------------------------
+// 192-bit two's complement, enough for |k| < 2^130
+struct S192 {
+  uint64_t w[3];
+};
+S192 s192_from(const uint64_t mag[4], bool neg) {
+  S192 r{{mag[0], mag[1], mag[2]}};
+  if (neg) {
+    unsigned __int128 c = 1;
+    for (int i = 0; i < 3; i++) {
+      c += (uint64_t)~r.w[i];
+      r.w[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  return r;
+}
+bool s192_zero(const S192& a) { return (a.w[0] | a.w[1] | a.w[2]) == 0; }
+void s192_sub_small(S192& a, int d) {  // a -= d, d in {-1, 0, 1}
+  if (d == 0) return;
+  if (d > 0) {
+    for (int i = 0; i < 3; i++)
+      if (a.w[i]-- != 0) break;
+  } else {
+    for (int i = 0; i < 3; i++)
+      if (++a.w[i] != 0) break;
+  }
+}
+void s192_sar1(S192& a) {
+  a.w[0] = (a.w[0] >> 1) | (a.w[1] << 63);
+  a.w[1] = (a.w[1] >> 1) | (a.w[2] << 63);
+  a.w[2] = (uint64_t)((int64_t)a.w[2] >> 1);
+}
+// digit (da, db) with z = a + b w congruent to it mod 4, if z is a unit mod 4
+bool unit_mod4(uint32_t a4, uint32_t b4, int& da, int& db) {
+  if (b4 == 0 && (a4 & 1u)) { da = a4 == 1 ? 1 : -1; db = 0; return true; }
+  if (a4 == 0 && (b4 & 1u)) { da = 0; db = b4 == 1 ? 1 : -1; return true; }
+  if (a4 == b4 && (a4 & 1u)) { da = db = a4 == 1 ? 1 : -1; return true; }
+  return false;
+}
+// Base-2 expansion of a + b w with digits 0 and the six units (+-1, +-w, +-(1+w)).  An odd z takes the
+// unit congruent to it mod 4 when there is one (the next digit is then 0); otherwise the sign that
+// leaves an even or unit-mod-4 successor.  About 56% of the positions are non-zero.
+int eisenstein_codes(S192 a, S192 b, uint32_t* codes, int max_positions) {
+  int pos = 0;
+  while (!(s192_zero(a) && s192_zero(b))) {
+    if (pos >= max_positions) return -1;
+    const uint32_t a4 = (uint32_t)a.w[0] & 3u, b4 = (uint32_t)b.w[0] & 3u;
+    int da = 0, db = 0;
+    if ((a4 | b4) & 1u) {
+      if (!unit_mod4(a4, b4, da, db)) {
+        const int ua = (int)(a4 & 1u), ub = (int)(b4 & 1u);
+        da = ua;
+        db = ub;
+        for (int sgn = 1; sgn >= -1; sgn -= 2) {
+          const int ta = sgn * ua, tb = sgn * ub;
+          const uint32_t na = (uint32_t)((a.w[0] - (uint64_t)(int64_t)ta) >> 1) & 3u;
+          const uint32_t nb = (uint32_t)((b.w[0] - (uint64_t)(int64_t)tb) >> 1) & 3u;
+          int x, y;
+          if (((na | nb) & 1u) == 0 || unit_mod4(na, nb, x, y)) {
+            da = ta;
+            db = tb;
+            break;
+          }
+        }
+      }
+      // (1,0) -> x, +y;  (0,1) -> zeta x, +y;  (1,1) -> zeta^2 x, -y;  negatives flip y
+      uint32_t sel, negy;
+      if (db == 0) { sel = 1; negy = da < 0; }
+      else if (da == 0) { sel = 2; negy = db < 0; }
+      else { sel = 3; negy = da > 0; }
+      codes[pos >> 3] |= (sel | (negy << 3)) << ((pos & 7) * 4);
+      s192_sub_small(a, da);
+      s192_sub_small(b, db);
+    }
+    s192_sar1(a);
+    s192_sar1(b);
+    pos++;
+  }
+  return pos;
+}
+
+template <int CURVE>
+int make_monic_plan(const uint64_t s_ark[4], MonicPlan& f) {
+  using HFs = host::HF<1 - CURVE>;
+  host::H4 a;
+  memcpy(a.v, s_ark, 32);
+  host::H4 ca = HFs::to_canon(a);
+  memset(&f, 0, sizeof f);
+  uint64_t k1[4], k2[4];
+  bool n1, n2;
+  glv_split<CURVE>(ca.v, k1, n1, k2, n2);
+  if (k1[3] | k2[3] | (k1[2] >> 4) | (k2[2] >> 4)) return fail(BPGPU_E_STATE, "GLV split produced an over-long half");
+  f.len = eisenstein_codes(s192_from(k1, n1), s192_from(k2, n2), f.codes, 136);
+  if (f.len < 0) return fail(BPGPU_E_STATE, "unit expansion too long");
+  return 0;
+}
+
+// out0[i] = g0[i] + s0 g0[i+n] (has_p) or s0 g0[i] (!has_p); same for vector 1 when nvec == 2
+int fold_monic_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64_t s0[4], const uint32_t* g1, uint32_t* o1,
+                      const uint64_t s1[4], int nvec, uint32_t n, int has_p) {
+  if (n == 0) return 0;
+  Ctx& C = g_ctx;
+  MonicPlan plans[2];
+  if (curve == BPGPU_PALLAS) {
+    TRY(make_monic_plan<0>(s0, plans[0]));
+    TRY(make_monic_plan<0>(nvec > 1 ? s1 : s0, plans[1]));
+  } else {
+    TRY(make_monic_plan<1>(s0, plans[0]));
+    TRY(make_monic_plan<1>(nvec > 1 ? s1 : s0, plans[1]));
+  }
+  TRY(C.fold_plans.ensure(sizeof(FoldPlan) * 2));
+  HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
+  HIP_TRY(hipMemcpyAsync(C.fold_plans.p, plans, sizeof plans, hipMemcpyHostToDevice, C.stream));
+  HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
+  dim3 grid(cdiv(n, 256), nvec);
+  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
+  if (curve == BPGPU_PALLAS)
+    k_fold_monic<0><<<grid, 256, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<MonicPlan>(), n, has_p);
+  else
+    k_fold_monic<1><<<grid, 256, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<MonicPlan>(), n, has_p);
+  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 size_t pow2_at_least(size_t n) {
   size_t p = 1;
   while (p < n) p <<= 1;
@@ -559,37 +685,118 @@ struct bpgpu_ipa {
   bool freeze_disabled;
   size_t n0;  // length at which the generators stopped being folded
   std::vector<std::array<uint64_t, 8>> pending;  // (x, x^-1) of the folds not applied to the points
+  // Common factors of the stored generators: the true vectors are muA * A and muB * B.  A fold
+  // x^-1 A_lo + x A_hi is done as A_lo + x^2 A_hi (one scalar multiplication per pair, k_fold_monic)
+  // with muA *= x^-1; the factors go into the MSM scalars (round_lr), into the weights when the
+  // generators freeze, and into the points themselves only when they are exported.
+  uint64_t muA[4], muB[4];  // ark form
+  bool mu_one;
+  uint32_t* scaled() const { return d_sc + 8ull * sc_scaled; }  // 2 np scratch scalars (mu a | mu b)
+  size_t sc_scaled;
   uint32_t* fsc() const { return d_sc + 8ull * (2 * np + 2); }
   uint32_t* wA() const { return fsc() + 8ull * 4 * freeze_cap; }
   uint32_t* wB() const { return wA() + 8ull * freeze_cap; }
 };
 
 namespace {
-// stop folding the generators: they stay as they are now (length s->len) and weights start at one
+template <int SF>
+void mu_mul(uint64_t mu[4], const uint64_t f[4]) {
+  host::H4 a, b;
+  memcpy(a.v, mu, 32);
+  memcpy(b.v, f, 32);
+  host::H4 r = host::HF<SF>::mul(a, b);
+  memcpy(mu, r.v, 32);
+}
+template <int SF>
+bool are_inverses(const uint64_t x[4], const uint64_t xi[4]) {
+  host::H4 a, b;
+  memcpy(a.v, x, 32);
+  memcpy(b.v, xi, 32);
+  return host::HF<SF>::eq(host::HF<SF>::mul(a, b), host::HF<SF>::one());
+}
+template <int SF>
+void sqr_ark(const uint64_t x[4], uint64_t out[4]) {
+  host::H4 a;
+  memcpy(a.v, x, 32);
+  host::H4 r = host::HF<SF>::sqr(a);
+  memcpy(out, r.v, 32);
+}
+void ipa_mu_reset(bpgpu_ipa* s) {
+  host::H4 one = s->curve == BPGPU_PALLAS ? host::HF<1>::one() : host::HF<0>::one();
+  memcpy(s->muA, one.v, 32);
+  memcpy(s->muB, one.v, 32);
+  s->mu_one = true;
+}
+// multiply the common factors into the stored generators (vector length s->len)
+int ipa_normalise(bpgpu_ipa* s) {
+  if (s->mu_one) return 0;
+  uint32_t* dA = s->d_pts;
+  uint32_t* dB = s->d_pts + 16ull * s->np;
+  TRY(fold_monic_launch(s->curve, dA, dA, s->muA, dB, dB, s->muB, 2, (uint32_t)s->len, 0));
+  ipa_mu_reset(s);
+  return 0;
+}
+// A' = x^-1 A_lo + x A_hi,  B' = x B_lo + x^-1 B_hi  on the stored generators, vectors of length 2n
+int ipa_fold_generators(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv[4], uint32_t n) {
+  uint32_t* dA = s->d_pts;
+  uint32_t* dB = s->d_pts + 16ull * s->np;
+  const bool pallas = s->curve == BPGPU_PALLAS;
+  if (pallas ? are_inverses<1>(x, x_inv) : are_inverses<0>(x, x_inv)) {
+    uint64_t x2[4], xi2[4];
+    if (pallas) {
+      sqr_ark<1>(x, x2);
+      sqr_ark<1>(x_inv, xi2);
+    } else {
+      sqr_ark<0>(x, x2);
+      sqr_ark<0>(x_inv, xi2);
+    }
+    TRY(fold_monic_launch(s->curve, dA, dA, x2, dB, dB, xi2, 2, n, 1));
+    if (pallas) {
+      mu_mul<1>(s->muA, x_inv);
+      mu_mul<1>(s->muB, x);
+    } else {
+      mu_mul<0>(s->muA, x_inv);
+      mu_mul<0>(s->muB, x);
+    }
+    s->mu_one = false;
+    return 0;
+  }
+  // (x, x_inv) are not inverses of each other: the two-scalar fold, on the true generators
+  const size_t len = s->len;
+  s->len = 2 * (size_t)n;
+  int rc = ipa_normalise(s);
+  s->len = len;
+  TRY(rc);
+  return fold_points_launch(s->curve, dA, dA, x_inv, x, dB, dB, x, x_inv, 2, n);
+}
+// stop folding the generators: they stay as they are now (length s->len); the weights start at the
+// common factors
 int ipa_freeze(bpgpu_ipa* s) {
   s->n0 = s->len;
   s->frozen = true;
   s->pending.clear();
-  const uint32_t cnt = (uint32_t)(2 * s->freeze_cap);
+  const uint32_t half = (uint32_t)s->freeze_cap;
+  FoldScalars m = make_fold_scalars(s->muA, s->muB);
   if (s->curve == BPGPU_PALLAS)
-    k_frozen_init<1><<<cdiv(cnt, 256), 256, 0, g_ctx.stream>>>(s->wA(), cnt);
+    k_frozen_init<1><<<cdiv(2 * half, 256), 256, 0, g_ctx.stream>>>(s->wA(), half, m);
   else
-    k_frozen_init<0><<<cdiv(cnt, 256), 256, 0, g_ctx.stream>>>(s->wA(), cnt);
+    k_frozen_init<0><<<cdiv(2 * half, 256), 256, 0, g_ctx.stream>>>(s->wA(), half, m);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 // apply the deferred point folds (export needs the folded generators themselves)
 int ipa_materialise(bpgpu_ipa* s) {
   if (!s->frozen) return 0;
+  const size_t final_len = s->len;
   size_t len = s->n0;
-  uint32_t* dA = s->d_pts;
-  uint32_t* dB = s->d_pts + 16ull * s->np;
+  int rc = 0;
   for (const auto& ch : s->pending) {
-    const uint64_t* x = ch.data();
-    const uint64_t* xi = ch.data() + 4;
-    TRY(fold_points_launch(s->curve, dA, dA, xi, x, dB, dB, x, xi, 2, (uint32_t)(len / 2)));
+    s->len = len;  // ipa_fold_generators may need to normalise at the current length
+    if ((rc = ipa_fold_generators(s, ch.data(), ch.data() + 4, (uint32_t)(len / 2))) != 0) break;
     len /= 2;
   }
+  s->len = final_len;
+  TRY(rc);
   s->pending.clear();
   s->frozen = false;
   s->freeze_disabled = true;
@@ -885,7 +1092,9 @@ int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gen
   s->frozen = false;
   s->freeze_disabled = g_ctx.freeze_len == 0;
   s->n0 = 0;
-  const size_t sc_words = (2 * np + 2 + 6 * s->freeze_cap) * 8;
+  s->sc_scaled = 2 * np + 2 + 6 * s->freeze_cap;
+  ipa_mu_reset(s);
+  const size_t sc_words = (s->sc_scaled + 2 * np) * 8;
   auto cleanup = [&]() {
     if (s->d_pts) (void)hipFree(s->d_pts);
     if (s->d_sc) (void)hipFree(s->d_sc);
@@ -974,13 +1183,28 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
     return 0;
   }
   plan.n = 2 * n + 1;
+  // the stored generators carry common factors: their MSM scalars are mu_A a and mu_B b
+  uint32_t sa = 0u, sb = np;  // scalar indices of a and b
+  if (!s->mu_one) {
+    sa = (uint32_t)s->sc_scaled;
+    sb = sa + np;
+    FoldScalars m = make_fold_scalars(s->muA, s->muB);
+    const uint32_t blocks = cdiv(2 * n, 256) < 2048 ? cdiv(2 * n, 256) : 2048;
+    if (s->curve == BPGPU_PALLAS)
+      k_scale_scalars<1><<<dim3(blocks, 2), 256, 0, g_ctx.stream>>>(s->d_sc, s->d_sc + 8ull * sa, s->d_sc + 8ull * np,
+                                                                   s->d_sc + 8ull * sb, m, 2 * n);
+    else
+      k_scale_scalars<0><<<dim3(blocks, 2), 256, 0, g_ctx.stream>>>(s->d_sc, s->d_sc + 8ull * sa, s->d_sc + 8ull * np,
+                                                                   s->d_sc + 8ull * sb, m, 2 * n);
+    HIP_TRY(hipGetLastError());
+  }
   // L = msm(A[n..] | B[..n] | Q,  a[..n] | b[n..] | c_L)   (bp_iter.rs:68-74)
-  plan.seg[0][0] = MsmSeg{n, 0u, n};
-  plan.seg[0][1] = MsmSeg{np, np + n, n};
+  plan.seg[0][0] = MsmSeg{n, sa, n};
+  plan.seg[0][1] = MsmSeg{np, sb + n, n};
   plan.seg[0][2] = MsmSeg{2 * np, 2 * np, 1};
   // R = msm(A[..n] | B[n..] | Q,  a[n..] | b[..n] | c_R)   (bp_iter.rs:75-81)
-  plan.seg[1][0] = MsmSeg{0u, n, n};
-  plan.seg[1][1] = MsmSeg{np + n, np, n};
+  plan.seg[1][0] = MsmSeg{0u, sa + n, n};
+  plan.seg[1][1] = MsmSeg{np + n, sb, n};
   plan.seg[1][2] = MsmSeg{2 * np, 2 * np + 1, 1};
   TRY(msm_dispatch(s->curve, s->d_pts, s->d_sc, plan, out));
   memcpy(l_xy_inf, out[0], 72);
@@ -1014,9 +1238,7 @@ int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv
     memcpy(ch.data() + 4, x_inv, 32);
     s->pending.push_back(ch);
   } else {
-    uint32_t* dA = s->d_pts;
-    uint32_t* dB = s->d_pts + 16ull * np;
-    TRY(fold_points_launch(s->curve, dA, dA, x_inv, x, dB, dB, x, x_inv, 2, n));
+    TRY(ipa_fold_generators(s, x, x_inv, n));
   }
   s->len = n;
   s->lr_done = false;
@@ -1041,7 +1263,10 @@ int bpgpu_ipa_export(bpgpu_ipa* s, uint64_t* a_gens_xyz, uint64_t* b_gens_xyz, u
   TRY(check_ready());
   if (!s) return fail(BPGPU_E_ARG, "null session");
   if (s->lr_done) return fail(BPGPU_E_STATE, "export between round_lr and round_fold");
-  if (a_gens_xyz || b_gens_xyz) TRY(ipa_materialise(s));
+  if (a_gens_xyz || b_gens_xyz) {
+    TRY(ipa_materialise(s));
+    TRY(ipa_normalise(s));
+  }
   const size_t n = s->len, np = s->np;
   hipStream_t st = g_ctx.stream;
   TRY(g_ctx.st_out.ensure(n * 96));

@@ -818,13 +818,14 @@ __global__ void __launch_bounds__(256) k_fold_scalars(uint32_t* __restrict__ v0,
 // generators are never needed (bpgpu_ipa_export replays the point folds if it is called).
 // Weights are kept in device form (value * 2^261), so montmul(ark scalar, weight) is an ark scalar.
 // ---------------------------------------------------------------------------
+// weights start at the common factors carried by the session: w[0, half) = m.lo, w[half, 2 half) = m.hi
 template <int SF>
-__global__ void __launch_bounds__(256) k_frozen_init(uint32_t* __restrict__ w, uint32_t count) {
+__global__ void __launch_bounds__(256) k_frozen_init(uint32_t* __restrict__ w, uint32_t half, FoldScalars m) {
   using F = Fp<SF>;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= count) return;
+  if (j >= 2 * half) return;
   uint32_t o[8];
-  F::store_packed(F::one(), o);
+  F::store_packed(j < half ? F::load_ark(m.lo) : F::load_ark(m.hi), o);
 #pragma unroll
   for (int k = 0; k < 8; k++) w[8ull * j + k] = o[k];
 }
@@ -999,6 +1000,130 @@ __global__ void __launch_bounds__(256) k_fold_points(const uint32_t* __restrict_
   }
   Aff r = E::to_affine(acc);
   IO::store_dev_affine(o + 16ull * i, r);
+}
+
+// ---------------------------------------------------------------------------
+// Monic generator fold:  out[i] = g[i] + s * g[i+n]   (has_p)   or   out[i] = s * g[i]   (!has_p).
+// The prover's session (bpgpu.hip, bpgpu_ipa) writes  x^-1 A_lo + x A_hi = x^-1 (A_lo + x^2 A_hi)  and
+// carries the common factor as a scalar, so a fold is ONE shared-scalar multiplication per pair.
+//   * s = k1 + k2 lambda (GLV) is an Eisenstein integer k1 + k2 w; it is expanded in base 2 with
+//     digits in {0, +-1, +-w, +-(1 + w)} (the units: every odd residue class mod 2 holds one).
+//     The matching points need no arithmetic: phi Q = (zeta x, y) and, because
+//     1 + lambda + lambda^2 = 0,  Q + phi Q = -phi^2 Q = (zeta^2 x, -y).  No table, no inversion.
+//   * the only inversion left (back to affine) is shared by the 256 lanes of the workgroup through
+//     a product tree in LDS.
+// 4-bit codes, position 0 = least significant:  code & 3: 0 none, 1: x, 2: zeta x, 3: zeta^2 x;
+// code & 8: use -y.
+// ---------------------------------------------------------------------------
+struct MonicPlan {
+  uint32_t codes[17];  // up to 136 positions, 8 per word
+  int len;
+};
+
+// 1 / v for every lane of a 256-thread workgroup (v != 0 in every lane); all lanes must call.
+template <int BF>
+__device__ __forceinline__ Fe block_inverse_256(const Fe& v, uint32_t (*tree)[9]) {
+  using F = Fp<BF>;
+  const uint32_t tid = threadIdx.x;
+  auto ld = [&](uint32_t node) {
+    Fe r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = (int32_t)tree[node][k];
+    return r;
+  };
+  auto st = [&](uint32_t node, const Fe& a) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) tree[node][k] = (uint32_t)a.l[k];
+  };
+  st(256 + tid, F::carry(v));
+  __syncthreads();
+  for (uint32_t w = 128; w >= 1; w >>= 1) {
+    if (tid < w) st(w + tid, F::mul(ld(2 * (w + tid)), ld(2 * (w + tid) + 1)));
+    __syncthreads();
+  }
+  // the root is inverted by one lane; which wave does it rotates with the workgroup so that
+  // co-resident workgroups do not queue their inversions on one SIMD
+  if (tid == 64 * (blockIdx.x & 3u)) st(1, F::inv(ld(1)));
+  __syncthreads();
+  for (uint32_t w = 1; w <= 128; w <<= 1) {
+    if (tid < w) {
+      const uint32_t p = w + tid;
+      Fe pi = ld(p), l = ld(2 * p), r = ld(2 * p + 1);
+      st(2 * p, F::mul(pi, r));
+      st(2 * p + 1, F::mul(pi, l));
+    }
+    __syncthreads();
+  }
+  return ld(256 + tid);
+}
+
+template <int BF>
+__global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* __restrict__ g0, uint32_t* __restrict__ o0,
+                                                    const uint32_t* __restrict__ g1, uint32_t* __restrict__ o1,
+                                                    const MonicPlan* __restrict__ plans, uint32_t n, int has_p) {
+  using F = Fp<BF>;
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  __shared__ uint32_t tree[512][9];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n;
+  const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
+  uint32_t* o = blockIdx.y == 0 ? o0 : o1;
+  const MonicPlan* f = plans + blockIdx.y;
+  Xyzz acc = E::identity();
+  if (active) {
+    Aff Q = IO::load_dev_affine(g + 16ull * (has_p ? i + n : i));
+    if (!Q.inf) {
+      // x never vanishes on a prime-order curve y^2 = x^3 + 5, so the three points are distinct
+      const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
+      const Fe x2 = F::mul(Q.x, zeta), x3 = F::mul(x2, zeta);
+      const Fe yn = F::carry(F::neg(Q.y));
+      for (int pos = f->len - 1; pos >= 0; pos--) {
+        acc = E::dbl(acc);
+        const uint32_t code = (f->codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;  // wave-uniform
+        const uint32_t sel = code & 3u;
+        if (sel) {
+          Aff t;
+          t.x = sel == 1 ? Q.x : (sel == 2 ? x2 : x3);
+          t.y = (code & 8u) ? yn : Q.y;
+          t.inf = false;
+          E::madd(acc, t);
+        }
+      }
+    }
+    if (has_p) E::madd(acc, IO::load_dev_affine(g + 16ull * i));
+  }
+  // back to affine: x = X / ZZ, y = Y / ZZZ with one shared inversion of ZZ * ZZZ
+  const bool fin = active && !acc.inf;
+  const Fe den = fin ? F::mul(acc.zz, acc.zzz) : F::one();
+  const Fe inv = block_inverse_256<BF>(den, tree);
+  if (active) {
+    Aff r;
+    r.inf = !fin;
+    r.x = F::mul(acc.x, F::mul(inv, acc.zzz));
+    r.y = F::mul(acc.y, F::mul(inv, acc.zz));
+    IO::store_dev_affine(o + 16ull * i, r);
+  }
+}
+
+// out[i] = s v[i] for two vectors in one launch (blockIdx.y: v0 with s.lo, v1 with s.hi)
+template <int SF>
+__global__ void __launch_bounds__(256) k_scale_scalars(const uint32_t* __restrict__ v0, uint32_t* __restrict__ o0,
+                                                       const uint32_t* __restrict__ v1, uint32_t* __restrict__ o1,
+                                                       FoldScalars s, uint32_t n) {
+  using F = Fp<SF>;
+  const uint32_t* v = blockIdx.y == 0 ? v0 : v1;
+  uint32_t* o = blockIdx.y == 0 ? o0 : o1;
+  const Fe m = blockIdx.y == 0 ? F::load_ark(s.lo) : F::load_ark(s.hi);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint4* pv = reinterpret_cast<const uint4*>(v + 8ull * i);
+    uint4 a0 = pv[0], a1 = pv[1];
+    uint32_t w[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    F::store_packed(F::mul(F::unpack(w), m), w);
+    uint4* po = reinterpret_cast<uint4*>(o + 8ull * i);
+    po[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    po[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
 }
 
 // Register-only multiply-add loop: sustained v_mad_u64_u32 issue rate (the integer

@@ -258,3 +258,52 @@ def test_bp_prove_deferred_fold_equivalence(ffi, freeze):
         assert (ga == fa).all() and (gb == fb).all()
     finally:
         ffi.set_freeze_len(1 << 16)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_session_monic_fold_edge_cases(ffi, c):
+    """The session folds generators as A_lo + x^2 A_hi with the factor x^-1 carried as a scalar
+    (k_fold_monic): L, R and the exported generators must equal the reference's
+    x^-1 A_lo + x A_hi (bp_iter.rs:97-104) for awkward challenges -- 1, -1, both cube roots of
+    unity (x^2 is then a unit of the GLV/Eisenstein expansion), a pair that is NOT an inverse pair
+    (two-scalar fallback) -- with identity padding and P == +-Q pairs among the generators."""
+    n = 32
+    lam = next(pow(g, (c.r - 1) // 3, c.r) for g in range(2, 50) if pow(g, (c.r - 1) // 3, c.r) != 1)
+    A = H.rand_points(c, n, 301)
+    B = H.rand_points(c, n, 302)
+    A[1] = None
+    A[n // 2 + 2] = None
+    A[3] = None
+    A[n // 2 + 3] = None
+    A[n // 2 + 4] = A[4]
+    A[n // 2 + 5] = pm.aff_neg(c, A[5])
+    B[n // 2 + 6] = B[6]
+    q = H.rand_points(c, 1, 303)
+    a = H.rand_scalars(c, n, 304)
+    b = H.rand_scalars(c, n, 305)
+    rnd = H.rand_scalars(c, 1, 306)[0]
+    pairs = [(1, 1), (c.r - 1, c.r - 1), (lam, lam * lam % c.r), (rnd, pow(rnd, -1, c.r)), (3, 5)]
+    ffi.set_freeze_len(0)
+    try:
+        sess = ffi.IpaSession(c.curve_id, H.jac_abi(c, A), H.jac_abi(c, B), H.jac_abi(c, q), H.scalars_abi(c, a),
+                              H.scalars_abi(c, b))
+        jA, jB = [pm.to_jac(p) for p in A], [pm.to_jac(p) for p in B]
+        for k, (x, xi) in enumerate(pairs):
+            m = len(a) // 2
+            c_l, c_r = pm.ip(c, a[:m], b[m:]), pm.ip(c, a[m:], b[:m])
+            want_l = pm.msm_naive(c, jA[m:] + jB[:m] + [pm.to_jac(q[0])], a[:m] + b[m:] + [c_l])
+            want_r = pm.msm_naive(c, jA[:m] + jB[m:] + [pm.to_jac(q[0])], a[m:] + b[:m] + [c_r])
+            l, r = sess.round_lr()
+            assert H.xy_inf_to_affine(c, l) == pm.jac_to_affine(c, want_l), k
+            assert H.xy_inf_to_affine(c, r) == pm.jac_to_affine(c, want_r), k
+            sess.round_fold(H.scalar_abi(c, x), H.scalar_abi(c, xi))
+            a, b = pm.fold_scalars(c, a, x, xi), pm.fold_scalars(c, b, xi, x)
+            jA, jB = pm.fold_points(c, jA, xi, x), pm.fold_points(c, jB, x, xi)
+            if k in (1, 2, 4):
+                gA, gB, ga, gb = sess.export()
+                assert H.jac_from_abi(c, gA) == [pm.jac_to_affine(c, p) for p in jA], k
+                assert H.jac_from_abi(c, gB) == [pm.jac_to_affine(c, p) for p in jB], k
+                assert H.scalars_from_abi(c, ga) == a and H.scalars_from_abi(c, gb) == b
+        sess.free()
+    finally:
+        ffi.set_freeze_len(1 << 16)
