@@ -8,6 +8,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -68,6 +71,79 @@ struct DevBuf {
   }
 };
 
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) HIP_TRY(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// One helper thread for the host tail of a two-MSM batch (a fresh std::async thread costs about as
+// much as the work it would take over).
+class Helper {
+ public:
+  ~Helper() { stop(); }  // a joinable std::thread must not reach its destructor (process exit without bpgpu_shutdown)
+  void start() {
+    if (th_.joinable()) return;
+    quit_ = false;
+    th_ = std::thread([this] {
+      std::unique_lock<std::mutex> lk(mu_);
+      for (;;) {
+        cv_.wait(lk, [this] { return quit_ || job_; });
+        if (quit_) return;
+        std::function<void()> j = std::move(job_);
+        job_ = nullptr;
+        lk.unlock();
+        j();
+        lk.lock();
+        busy_ = false;
+        done_.notify_all();
+      }
+    });
+  }
+  void stop() {
+    if (!th_.joinable()) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  void submit(std::function<void()> j) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = std::move(j);
+      busy_ = true;
+    }
+    cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return !busy_; });
+  }
+
+ private:
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::function<void()> job_;
+  bool busy_ = false, quit_ = false;
+};
+
 struct Ctx {
   bool ready = false;
   int device = 0;
@@ -79,10 +155,11 @@ struct Ctx {
   int num_cus = 256;
   float msm_ms[8] = {};
   // MSM workspace (grow-only)
-  DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy, bcount;
+  DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy, bcount, redtmp;
   // staging for host-buffer entry points
   DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip, fold_plans;
-  std::vector<uint32_t> h_winsum;
+  Helper helper;
+  PinnedBuf h_winsum;  // window sums land here (pinned: the copy is a plain DMA)
 };
 
 Ctx g_ctx;
@@ -194,6 +271,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const uint64_t slots = (uint64_t)plan.M * plan.n;
   // bucket reduction: runs of S = 2^s buckets, at most 8192 runs per window
   int s = c - 1 < 2 ? c - 1 : 2;
+  if (NB >= (400u << 10) && c - 1 >= 3) s = 3;  // many buckets: longer runs halve the second stage's work
   if (c - 1 - s > 13) s = c - 1 - 13;
   const uint32_t nruns = NB >> s;
   const uint32_t runs_per_window = B >> s;
@@ -265,17 +343,35 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[4], st));
   k_reduce1<BF><<<cdiv(nruns, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
-  k_reduce2<BF><<<dim3(comps, plan.M * W), 512, 0, st>>>(C.partial.as<uint32_t>(), C.winsum.as<uint32_t>(),
-                                                          runs_per_window);
+  {
+    // slices per component: about 2048 waves in all, at least one value per lane
+    const uint32_t outputs = (uint32_t)(comps * plan.M * W), half = runs_per_window >> 1;
+    uint32_t slices = 1;
+    while (slices < 64 && 2 * slices * outputs <= 2048 && 2 * slices * 64 <= half) slices *= 2;
+    TRY(C.redtmp.ensure((size_t)outputs * slices * 128));
+    k_reduce2<BF><<<dim3(comps, plan.M * W, cdiv(slices, 4)), 256, 0, st>>>(
+        C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window, slices);
+    if (slices > 1)
+      k_reduce3<BF><<<cdiv(outputs * slices, 256), 256, 0, st>>>(C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), outputs,
+                                                                  slices);
+  }
   HIP_TRY(hipEventRecord(C.ev[5], st));
-  C.h_winsum.resize((size_t)plan.M * W * comps * 32);
-  HIP_TRY(hipMemcpyAsync(C.h_winsum.data(), C.winsum.p, (size_t)plan.M * W * comps * 128, hipMemcpyDeviceToHost, st));
+  TRY(C.h_winsum.ensure((size_t)plan.M * W * comps * 128));
+  HIP_TRY(hipMemcpyAsync(C.h_winsum.p, C.winsum.p, (size_t)plan.M * W * comps * 128, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   auto t0 = std::chrono::steady_clock::now();
-  for (int m = 0; m < plan.M; m++) {
-    host::HPoint<BF> r = horner<BF>(C.h_winsum.data() + (size_t)m * W * comps * 32, W, c, s, nbits);
-    write_xy_inf<BF>(r, out[m]);
+  {
+    // Horner tail: one host thread per MSM of the batch (the second one on a helper thread)
+    const uint32_t* hw = (const uint32_t*)C.h_winsum.p;
+    const size_t stride = (size_t)W * comps * 32;
+    host::HPoint<BF> second;
+    if (plan.M > 1) C.helper.submit([&, hw, stride, W, c, s, nbits] { second = horner<BF>(hw + stride, W, c, s, nbits); });
+    write_xy_inf<BF>(horner<BF>(hw, W, c, s, nbits), out[0]);
+    if (plan.M > 1) {
+      C.helper.wait();
+      write_xy_inf<BF>(second, out[1]);
+    }
   }
   auto t1 = std::chrono::steady_clock::now();
   float ms;
@@ -825,6 +921,7 @@ int bpgpu_init(int device) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   g_ctx.num_cus = prop.multiProcessorCount;
   g_ctx.device = device;
+  g_ctx.helper.start();
   g_ctx.ready = true;
   return 0;
 }
@@ -834,9 +931,11 @@ void bpgpu_shutdown(void) {
   if (!g_ctx.ready) return;
   (void)hipSetDevice(g_ctx.device);
   (void)hipStreamSynchronize(g_ctx.stream);
-  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial, &g_ctx.heavy, &g_ctx.bcount,
+  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial, &g_ctx.heavy, &g_ctx.bcount, &g_ctx.redtmp,
                     &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip, &g_ctx.fold_plans})
     b->release();
+  g_ctx.h_winsum.release();
+  g_ctx.helper.stop();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);
   for (auto& e : g_ctx.op_ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(g_ctx.stream);

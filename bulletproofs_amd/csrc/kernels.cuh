@@ -548,21 +548,25 @@ __global__ void __launch_bounds__(256) k_reduce1(const uint32_t* __restrict__ bs
   IO::store_dev_xyzz(partial + 64ull * r + 32, running);
 }
 
-// grid = (2 + nbits, windows); components 0 and 1 = the two halves of P, component 2+i = U_i.
-// Every workgroup sums per/2 values: lanes first, then the wave, then the 8 waves.  out: ark-form XYZZ.
+// grid = (2 + nbits, windows, ceil(slices / 4)); components 0 and 1 = the two halves of P, component
+// 2+i = U_i.  A component sums per/2 values; it is cut into `slices` slices, one wave each: lanes
+// first (every lane busy), then the wave.  slices == 1 writes the result (ark-form XYZZ) to out,
+// otherwise the slice sums go to tmp and k_reduce3 adds them up.
 template <int BF>
-__global__ void __launch_bounds__(512) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* __restrict__ out,
-                                                 uint32_t per) {
+__global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tmp,
+                                                 uint32_t* __restrict__ out, uint32_t per, uint32_t slices) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
-  __shared__ uint32_t sh[8 * 33];
-  const uint32_t comp = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t comp = blockIdx.x, w = blockIdx.y, lane = threadIdx.x & 63u;
+  const uint32_t slice = blockIdx.z * 4 + (threadIdx.x >> 6);
+  if (slice >= slices) return;
   const uint32_t half = per >> 1;  // per is a power of two; per = 1 leaves component 1.. empty
   Xyzz acc = E::identity();
   if (per == 1) {
-    if (comp == 0 && tid == 0) acc = IO::load_dev_xyzz(partial + 64ull * w);
+    if (comp == 0 && lane == 0) acc = IO::load_dev_xyzz(partial + 64ull * w);
   } else {
-    for (uint32_t j = tid; j < half; j += 512) {
+    const uint32_t len = half / slices, j0 = slice * len;  // slices <= half, both powers of two
+    for (uint32_t j = j0 + lane; j < j0 + len; j += 64) {
       uint32_t r, which;
       if (comp < 2) {
         r = comp * half + j;
@@ -576,14 +580,39 @@ __global__ void __launch_bounds__(512) k_reduce2(const uint32_t* __restrict__ pa
     }
   }
   acc = wave_sum_xyzz<BF>(acc);
-  if (lane == 0) IO::store_dev_xyzz(sh + 33 * wave, acc);
-  __syncthreads();
-  if (wave == 0) {
-    Xyzz p = E::identity();
-    if (lane < 8) p = IO::load_dev_xyzz(sh + 33 * lane);
-    p = wave_sum_xyzz<BF, 4>(p);
-    if (lane == 0) IO::store_ark_xyzz(out + 32ull * ((uint64_t)w * gridDim.x + comp), p);
+  if (lane == 0) {
+    const uint64_t o = (uint64_t)w * gridDim.x + comp;
+    if (slices == 1)
+      IO::store_ark_xyzz(out + 32ull * o, acc);
+    else
+      IO::store_dev_xyzz(tmp + 32ull * (o * slices + slice), acc);
   }
+}
+
+// out[o] = sum of the `slices` (a power of two, 2..64) slice sums of output o; one lane per slice sum
+template <int BF>
+__global__ void __launch_bounds__(256) k_reduce3(const uint32_t* __restrict__ tmp, uint32_t* __restrict__ out,
+                                                 uint32_t outputs, uint32_t slices) {
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t o = t / slices;
+  Xyzz acc = E::identity();
+  if (o < outputs) acc = IO::load_dev_xyzz(tmp + 32ull * t);
+#pragma unroll 1
+  for (uint32_t off = slices >> 1; off >= 1; off >>= 1) {
+    Xyzz v;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      v.x.l[i] = __shfl_down(acc.x.l[i], off, 64);
+      v.y.l[i] = __shfl_down(acc.y.l[i], off, 64);
+      v.zz.l[i] = __shfl_down(acc.zz.l[i], off, 64);
+      v.zzz.l[i] = __shfl_down(acc.zzz.l[i], off, 64);
+    }
+    v.inf = __shfl_down((int)acc.inf, off, 64) != 0;
+    acc = E::add(acc, v);
+  }
+  if (o < outputs && (t & (slices - 1)) == 0) IO::store_ark_xyzz(out + 32ull * o, acc);
 }
 
 // ---------------------------------------------------------------------------

@@ -8,6 +8,8 @@ from bulletproofs_amd import ffi, ark_bp
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ffi.init(0)
+if len(sys.argv) > 2:
+    ffi.set_window_bits(int(sys.argv[2]))
 n = 1 << k
 pts = bench.synth_points(ffi, 0, 2 * n + 1, seed=5)
 A, B, q = pts[:n], pts[n:2 * n], pts[2 * n:]
