@@ -80,6 +80,44 @@ def bp_prove(curve, a_gens, b_gens, ip_gen, a, b, fs_seed: bytes):
     return dict(ls=ls[:k], rs=rs[:k], challenges=ch[:k], final_a=fa, final_b=fb, prove_ms=ms.value)
 
 
+class DeviceGens:
+    """IpaGens uploaded once (host mirror: ark_bp.hpp DeviceGens); pass to bp_prove_cached."""
+
+    def __init__(self, curve, a_gens, b_gens, ip_gen):
+        A, B, q = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12)
+        assert len(A) == len(B)
+        self.curve, self.n = curve, len(A)
+        h = ctypes.c_void_p()
+        _check(load().arkbp_gens_upload(curve, _p(A), _p(B), _p(q), c_size_t(self.n), ctypes.byref(h)))
+        self.h = h.value
+
+    def free(self):
+        if self.h:
+            load().arkbp_gens_free(ctypes.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def bp_prove_cached(gens: DeviceGens, a, b, fs_seed: bytes):
+    """Bp::prove with the generators already in HBM -> same dict as bp_prove."""
+    a, b = _u64(a, 4), _u64(b, 4)
+    n = len(a)
+    kmax = max(1, (max(n, 1) - 1).bit_length())
+    ls, rs = np.zeros((kmax, 12), np.uint64), np.zeros((kmax, 12), np.uint64)
+    ch = np.zeros((kmax, 4), np.uint64)
+    fa, fb = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    ms = c_double()
+    k = _check(load().arkbp_bp_prove_cached(gens.curve, ctypes.c_void_p(gens.h), _p(a), _p(b), c_size_t(n), _p(seed),
+                                            _p(ls), _p(rs), _p(ch), _p(fa), _p(fb), ctypes.byref(ms)))
+    return dict(ls=ls[:k], rs=rs[:k], challenges=ch[:k], final_a=fa, final_b=fb, prove_ms=ms.value)
+
+
 def bp_verify(curve, a_gens, b_gens, ip_gen, result, proof, fs_seed: bytes):
     """Bp::verify: returns None, raises Panic where the reference's assert_eq! fails."""
     A, B, q, res = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(result, 12)

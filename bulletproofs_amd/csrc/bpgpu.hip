@@ -1170,13 +1170,13 @@ int bpgpu_fold_points(int curve, const uint64_t* g_xyz, size_t n_out, const uint
 }
 
 // ---- IPA prover session -----------------------------------------------------
-int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
-                    const uint64_t* a, const uint64_t* b, size_t n, bpgpu_ipa** out) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  TRY(check_ready());
-  TRY(check_curve(curve));
-  if (!out || !ip_gen_xyz) return fail(BPGPU_E_ARG, "null pointer");
-  if (n && (!a_gens_xyz || !b_gens_xyz || !a || !b)) return fail(BPGPU_E_ARG, "null pointer");
+// Shared by the two begin calls: generators come from host memory (ark Jacobian, converted on the
+// device) or from device memory (dev affine, as bpgpu_points_to_device leaves them); the witness
+// always comes from the host.
+static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
+                            const void* d_a_gens, const void* d_b_gens, const void* d_ip_gen, const uint64_t* a,
+                            const uint64_t* b, size_t n, bpgpu_ipa** out) {
+  const bool from_device = d_ip_gen != nullptr;
   if (n > (1u << 30)) return fail(BPGPU_E_ARG, "n too large");
   // zero_pad_to_two_power (util/mod.rs:137-144): next power of two, at least 1
   size_t np = pow2_at_least(n < 1 ? 1 : n);
@@ -1214,24 +1214,33 @@ int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gen
       rc = fail(BPGPU_E_HIP, "hipMemsetAsync failed");
       break;
     }
-    if ((rc = g_ctx.st_pts_in.ensure((2 * n + 1) * 96)) != 0) break;
-    uint8_t* stg = (uint8_t*)g_ctx.st_pts_in.p;
     if (n) {
-      if (hipMemcpyAsync(stg, a_gens_xyz, n * 96, hipMemcpyHostToDevice, st) != hipSuccess ||
-          hipMemcpyAsync(stg + n * 96, b_gens_xyz, n * 96, hipMemcpyHostToDevice, st) != hipSuccess ||
-          hipMemcpyAsync(s->d_sc, a, n * 32, hipMemcpyHostToDevice, st) != hipSuccess ||
+      if (hipMemcpyAsync(s->d_sc, a, n * 32, hipMemcpyHostToDevice, st) != hipSuccess ||
           hipMemcpyAsync(s->d_sc + 8 * np, b, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) {
         rc = fail(BPGPU_E_HIP, "upload failed");
         break;
       }
     }
-    if (hipMemcpyAsync(stg + 2 * n * 96, ip_gen_xyz, 96, hipMemcpyHostToDevice, st) != hipSuccess) {
-      rc = fail(BPGPU_E_HIP, "upload failed");
-      break;
+    if (from_device) {
+      if ((n && (hipMemcpyAsync(s->d_pts, d_a_gens, n * 64, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                 hipMemcpyAsync(s->d_pts + 16 * np, d_b_gens, n * 64, hipMemcpyDeviceToDevice, st) != hipSuccess)) ||
+          hipMemcpyAsync(s->d_pts + 32 * np, d_ip_gen, 64, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        rc = fail(BPGPU_E_HIP, "device copy failed");
+        break;
+      }
+    } else {
+      if ((rc = g_ctx.st_pts_in.ensure((2 * n + 1) * 96)) != 0) break;
+      uint8_t* stg = (uint8_t*)g_ctx.st_pts_in.p;
+      if ((n && (hipMemcpyAsync(stg, a_gens_xyz, n * 96, hipMemcpyHostToDevice, st) != hipSuccess ||
+                 hipMemcpyAsync(stg + n * 96, b_gens_xyz, n * 96, hipMemcpyHostToDevice, st) != hipSuccess)) ||
+          hipMemcpyAsync(stg + 2 * n * 96, ip_gen_xyz, 96, hipMemcpyHostToDevice, st) != hipSuccess) {
+        rc = fail(BPGPU_E_HIP, "upload failed");
+        break;
+      }
+      if ((rc = points_in(curve, (uint32_t*)stg, s->d_pts, n, 0)) != 0) break;
+      if ((rc = points_in(curve, (uint32_t*)(stg + n * 96), s->d_pts + 16 * np, n, 0)) != 0) break;
+      if ((rc = points_in(curve, (uint32_t*)(stg + 2 * n * 96), s->d_pts + 32 * np, 1, 0)) != 0) break;
     }
-    if ((rc = points_in(curve, (uint32_t*)stg, s->d_pts, n, 0)) != 0) break;
-    if ((rc = points_in(curve, (uint32_t*)(stg + n * 96), s->d_pts + 16 * np, n, 0)) != 0) break;
-    if ((rc = points_in(curve, (uint32_t*)(stg + 2 * n * 96), s->d_pts + 32 * np, 1, 0)) != 0) break;
     if (np <= s->freeze_cap && !s->freeze_disabled && np > 1 && (rc = ipa_freeze(s)) != 0) break;
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(BPGPU_E_HIP, "sync failed");
   } while (0);
@@ -1241,6 +1250,26 @@ int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gen
   }
   *out = s;
   return 0;
+}
+
+int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
+                    const uint64_t* a, const uint64_t* b, size_t n, bpgpu_ipa** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!out || !ip_gen_xyz) return fail(BPGPU_E_ARG, "null pointer");
+  if (n && (!a_gens_xyz || !b_gens_xyz || !a || !b)) return fail(BPGPU_E_ARG, "null pointer");
+  return ipa_begin_common(curve, a_gens_xyz, b_gens_xyz, ip_gen_xyz, nullptr, nullptr, nullptr, a, b, n, out);
+}
+
+int bpgpu_ipa_begin_device(int curve, const void* d_a_gens, const void* d_b_gens, const void* d_ip_gen, const uint64_t* a,
+                           const uint64_t* b, size_t n, bpgpu_ipa** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!out || !d_ip_gen) return fail(BPGPU_E_ARG, "null pointer");
+  if (n && (!d_a_gens || !d_b_gens || !a || !b)) return fail(BPGPU_E_ARG, "null pointer");
+  return ipa_begin_common(curve, nullptr, nullptr, nullptr, d_a_gens, d_b_gens, d_ip_gen, a, b, n, out);
 }
 
 size_t bpgpu_ipa_len(const bpgpu_ipa* s) { return s ? s->len : 0; }

@@ -40,6 +40,7 @@ SIGNATURES = {
     "bpgpu_fold_scalars_device": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bpgpu_fold_points_device": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bpgpu_ipa_begin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "bpgpu_ipa_begin_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
     "bpgpu_ipa_len": (c_size_t, [c_void_p]),
     "bpgpu_ipa_round_lr": (c_int, [c_void_p, c_void_p, c_void_p]),
     "bpgpu_ipa_round_fold": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -279,6 +280,20 @@ class IpaSession:
         _check(load().bpgpu_ipa_begin(curve, _ptr(A), _ptr(B), _ptr(q), _ptr(a), _ptr(b), n, ctypes.byref(h)))
         self.h = h.value
         self.curve = curve
+
+    @classmethod
+    def from_device(cls, curve, d_a_gens, d_b_gens, d_ip_gen, a, b):
+        """Generators already in HBM (DeviceBuffers of dev affine points, see points_to_device)."""
+        a, b = _u64(a, 4), _u64(b, 4)
+        n = len(a)
+        assert len(b) == n and d_a_gens.nbytes >= 64 * n and d_b_gens.nbytes >= 64 * n
+        h = c_void_p()
+        _check(load().bpgpu_ipa_begin_device(curve, d_a_gens.ptr, d_b_gens.ptr, d_ip_gen.ptr, _ptr(a), _ptr(b), n,
+                                             ctypes.byref(h)))
+        self = cls.__new__(cls)
+        self.h = h.value
+        self.curve = curve
+        return self
 
     def __len__(self):
         return load().bpgpu_ipa_len(self.h)

@@ -307,6 +307,43 @@ struct IpaWitness {
   std::vector<Fr> a, b;
 };
 
+// IpaGens held in HBM across proofs.  The generators are fixed public parameters
+// (src/relations/ipa.rs:28-36 samples them once per size), so a prover that makes many proofs
+// uploads them once; Bp::prove then moves only the witness.  No counterpart in the reference,
+// which keeps everything in host memory.
+struct DeviceGens {
+  int curve;
+  size_t n;
+  void *a = nullptr, *b = nullptr, *q = nullptr;
+  DeviceGens(int curve_, const IpaGens& g) : curve(curve_), n(g.a_gens.size()) {
+    if (g.b_gens.size() != n) throw Panic("assertion failed: vector sizes");
+    try {
+      check(bpgpu_dev_alloc((n ? n : 1) * 64, &a));
+      check(bpgpu_dev_alloc((n ? n : 1) * 64, &b));
+      check(bpgpu_dev_alloc(64, &q));
+      if (n) {
+        check(bpgpu_points_to_device(curve, g.a_gens.data()->v, n, 0, a));
+        check(bpgpu_points_to_device(curve, g.b_gens.data()->v, n, 0, b));
+      }
+      check(bpgpu_points_to_device(curve, g.ip_gen.v, 1, 0, q));
+    } catch (...) {
+      release();
+      throw;
+    }
+  }
+  DeviceGens(const DeviceGens&) = delete;
+  DeviceGens& operator=(const DeviceGens&) = delete;
+  ~DeviceGens() { release(); }
+
+ private:
+  void release() {
+    if (a) (void)bpgpu_dev_free(a);
+    if (b) (void)bpgpu_dev_free(b);
+    if (q) (void)bpgpu_dev_free(q);
+    a = b = q = nullptr;
+  }
+};
+
 template <int CURVE>
 G zero_point() {
   uint64_t o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
@@ -347,15 +384,23 @@ struct Bp {
 
   // bp_iter.rs:49-128.  The vectors go to HBM once; per round only L, R come back and
   // x, x^-1 go down.  Optionally reports the challenges (not part of the reference's proof).
+  // `cached`, when given, must hold instance.gens (DeviceGens above): the generators are then not
+  // uploaded again.
   static BpProof prove(const IpaInstance& instance, const IpaWitness& witness, FiatShamirRng& fs,
-                       std::vector<Fr>* challenges_out = nullptr) {
+                       std::vector<Fr>* challenges_out = nullptr, const DeviceGens* cached = nullptr) {
     const size_t n = witness.a.size();
     if (witness.b.size() != n || instance.gens.a_gens.size() != n || instance.gens.b_gens.size() != n)
       throw Panic("assertion failed: vector sizes");
     bpgpu_ipa* sess = nullptr;
-    check(bpgpu_ipa_begin(CURVE, n ? instance.gens.a_gens.data()->v : nullptr, n ? instance.gens.b_gens.data()->v : nullptr,
-                          instance.gens.ip_gen.v, n ? witness.a.data()->v : nullptr, n ? witness.b.data()->v : nullptr, n,
-                          &sess));
+    if (cached) {
+      if (cached->n != n || cached->curve != CURVE) throw Panic("assertion failed: cached generators do not match");
+      check(bpgpu_ipa_begin_device(CURVE, cached->a, cached->b, cached->q, n ? witness.a.data()->v : nullptr,
+                                   n ? witness.b.data()->v : nullptr, n, &sess));
+    } else {
+      check(bpgpu_ipa_begin(CURVE, n ? instance.gens.a_gens.data()->v : nullptr,
+                            n ? instance.gens.b_gens.data()->v : nullptr, instance.gens.ip_gen.v,
+                            n ? witness.a.data()->v : nullptr, n ? witness.b.data()->v : nullptr, n, &sess));
+    }
     BpProof proof;
     try {
       while (bpgpu_ipa_len(sess) > 1) {

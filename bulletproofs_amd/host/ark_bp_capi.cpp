@@ -71,6 +71,32 @@ int bp_prove(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_
   return (int)pf.ls.size();
 }
 
+// Bp::prove with the generators already in HBM (handle from arkbp_gens_upload)
+template <int CURVE>
+int bp_prove_cached(const DeviceGens* dg, const uint64_t* a, const uint64_t* b, size_t n, const uint8_t* fs_seed,
+                    uint64_t* ls, uint64_t* rs, uint64_t* challenges, uint64_t* final_a, uint64_t* final_b,
+                    double* prove_ms) {
+  IpaInstance x;  // the host copy of the generators is not needed: sizes only
+  x.gens.vec_size = n;
+  x.gens.a_gens.resize(n);
+  x.gens.b_gens.resize(n);
+  IpaWitness w = make_witness(a, b, n);
+  FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
+  std::vector<Fr> ch;
+  auto t0 = std::chrono::steady_clock::now();
+  BpProof pf = Bp<CURVE>::prove(x, w, fs, &ch, dg);
+  auto t1 = std::chrono::steady_clock::now();
+  if (prove_ms) *prove_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  for (size_t i = 0; i < pf.ls.size(); i++) {
+    std::memcpy(ls + 12 * i, pf.ls[i].v, 96);
+    std::memcpy(rs + 12 * i, pf.rs[i].v, 96);
+    if (challenges) std::memcpy(challenges + 4 * i, ch[i].v, 32);
+  }
+  std::memcpy(final_a, pf.final_a.v, 32);
+  std::memcpy(final_b, pf.final_b.v, 32);
+  return (int)pf.ls.size();
+}
+
 template <int CURVE>
 int bp_verify(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result, size_t n,
               const uint64_t* ls, const uint64_t* rs, size_t k, const uint64_t* final_a, const uint64_t* final_b,
@@ -164,6 +190,25 @@ int arkbp_bp_prove(int curve, const uint64_t* a_gens, const uint64_t* b_gens, co
                    uint64_t* final_a, uint64_t* final_b, double* prove_ms) {
   return guarded([&] {
     return BY_CURVE(bp_prove, a_gens, b_gens, ip_gen, a, b, n, fs_seed, ls, rs, challenges, final_a, final_b, prove_ms);
+  });
+}
+// generators to HBM once, for any number of arkbp_bp_prove_cached calls
+int arkbp_gens_upload(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, size_t n,
+                      void** handle) {
+  return guarded([&] {
+    if (curve != 0 && curve != 1) throw Panic("unknown curve");
+    IpaInstance x = make_instance(a_gens, b_gens, ip_gen, nullptr, n);
+    *handle = new DeviceGens(curve, x.gens);
+    return 0;
+  });
+}
+void arkbp_gens_free(void* handle) { delete static_cast<DeviceGens*>(handle); }
+int arkbp_bp_prove_cached(int curve, const void* handle, const uint64_t* a, const uint64_t* b, size_t n,
+                          const uint8_t* fs_seed, uint64_t* ls, uint64_t* rs, uint64_t* challenges, uint64_t* final_a,
+                          uint64_t* final_b, double* prove_ms) {
+  return guarded([&] {
+    const DeviceGens* dg = static_cast<const DeviceGens*>(handle);
+    return BY_CURVE(bp_prove_cached, dg, a, b, n, fs_seed, ls, rs, challenges, final_a, final_b, prove_ms);
   });
 }
 // 0 = accepted; -100 = the reference's verify would have panicked

@@ -126,6 +126,13 @@ typedef struct bpgpu_ipa bpgpu_ipa;
 int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz,
                     const uint64_t* ip_gen_xyz, const uint64_t* a, const uint64_t* b, size_t n,
                     bpgpu_ipa** out);
+/* Same session, generators already in HBM: the IPA generators are fixed public parameters
+ * (src/relations/ipa.rs:28-36 samples them once per relation size), so a prover that makes many
+ * proofs uploads them once with bpgpu_points_to_device and pays only the witness upload per
+ * proof.  d_a_gens, d_b_gens: n device affine points each; d_ip_gen: one.  The session works on
+ * its own copy; the caller's arrays are not modified. */
+int bpgpu_ipa_begin_device(int curve, const void* d_a_gens, const void* d_b_gens, const void* d_ip_gen,
+                           const uint64_t* a, const uint64_t* b, size_t n, bpgpu_ipa** out);
 /* current (padded) vector length; 1 when the loop is finished */
 size_t bpgpu_ipa_len(const bpgpu_ipa* s);
 int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9]);

@@ -91,3 +91,36 @@ def test_msm_zip_and_ip_assert(bp):
     with pytest.raises(bp.Panic):                                                      # assert_eq!(a.len(), b.len())
         bp.ip(0, sc[:3], sc[:4])
     assert (bp.ip(0, sc[:20], sc[20:]) == co.ip(0, sc[:20], sc[20:])).all()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 5, 64, 300])
+def test_prove_with_device_resident_generators(bp, c, n):
+    """Generators uploaded once (DeviceGens / bpgpu_ipa_begin_device), two proofs with different
+    witnesses: each is bit-identical to Bp::prove from host vectors and to the oracle's, and the
+    cached generators are left untouched by the sessions that used them."""
+    cid = c.curve_id
+    A, B, q, a, b, seed = co.ipa_inputs(cid, n)
+    gens = bp.DeviceGens(cid, A, B, q)
+    try:
+        for k in range(2):
+            a_k = a if k == 0 else np.ascontiguousarray(b[::-1])
+            want = bp.bp_prove(cid, A, B, q, a_k, b, seed)
+            got = bp.bp_prove_cached(gens, a_k, b, seed)
+            for key in ("ls", "rs", "challenges", "final_a", "final_b"):
+                assert (got[key] == want[key]).all(), (k, key)
+        # against the oracle too (zero-padded as bp_iter.rs:59-62 does)
+        np_ = 1 << max(0, (n - 1).bit_length())
+        pad_p = np.tile(co.normalise(cid, np.zeros((1, 12), np.uint64)), (np_ - n, 1))
+        zs = np.zeros((np_ - n, 4), np.uint64)
+        ls, rs, ch, fa, fb = co.bp_prove(cid, np.concatenate([A, pad_p]), np.concatenate([B, pad_p]), q,
+                                         np.concatenate([a_k, zs]), np.concatenate([b, zs]), seed, threads=4)
+        assert (got["ls"] == ls).all() and (got["rs"] == rs).all() and (got["final_a"] == fa).all()
+    finally:
+        gens.free()
+    with pytest.raises(bp.Panic):   # cached generators of another size
+        g2 = bp.DeviceGens(cid, A, B, q)
+        try:
+            bp.bp_prove_cached(g2, np.concatenate([a, a]), np.concatenate([b, b]), seed)
+        finally:
+            g2.free()
