@@ -337,7 +337,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   k_bin_place<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
                                           C.offs.as<uint32_t>(), C.bcount.as<uint32_t>(), C.sorted.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[3], st));
-  k_accum<BF><<<C.num_cus * 2, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
+  k_accum<BF><<<C.num_cus * BP_ACCUM_WAVES, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
                                              C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits, hv,
                                              chunk_counter);
   k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
@@ -729,9 +729,17 @@ int make_monic_plan(const uint64_t s_ark[4], MonicPlan& f) {
   return 0;
 }
 
+// o0[i] = p0[i] + s0 q0[i] (has_p) or s0 q0[i] (!has_p); same for vector 1 when nvec == 2
+int fold_monic_pq(int curve, const uint32_t* p0, const uint32_t* q0, uint32_t* o0, const uint64_t s0[4], const uint32_t* p1,
+                  const uint32_t* q1, uint32_t* o1, const uint64_t s1[4], int nvec, uint32_t n, int has_p);
 // out0[i] = g0[i] + s0 g0[i+n] (has_p) or s0 g0[i] (!has_p); same for vector 1 when nvec == 2
 int fold_monic_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64_t s0[4], const uint32_t* g1, uint32_t* o1,
                       const uint64_t s1[4], int nvec, uint32_t n, int has_p) {
+  const size_t off = has_p ? 16ull * n : 0;
+  return fold_monic_pq(curve, g0, g0 + off, o0, s0, g1, g1 + off, o1, s1, nvec, n, has_p);
+}
+int fold_monic_pq(int curve, const uint32_t* p0, const uint32_t* q0, uint32_t* o0, const uint64_t s0[4], const uint32_t* p1,
+                  const uint32_t* q1, uint32_t* o1, const uint64_t s1[4], int nvec, uint32_t n, int has_p) {
   if (n == 0) return 0;
   Ctx& C = g_ctx;
   MonicPlan plans[2];
@@ -749,9 +757,9 @@ int fold_monic_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64_
   dim3 grid(cdiv(n, 256), nvec);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
   if (curve == BPGPU_PALLAS)
-    k_fold_monic<0><<<grid, 256, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<MonicPlan>(), n, has_p);
+    k_fold_monic<0><<<grid, 256, 0, C.stream>>>(p0, q0, o0, p1, q1, o1, C.fold_plans.as<MonicPlan>(), n, has_p);
   else
-    k_fold_monic<1><<<grid, 256, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<MonicPlan>(), n, has_p);
+    k_fold_monic<1><<<grid, 256, 0, C.stream>>>(p0, q0, o0, p1, q1, o1, C.fold_plans.as<MonicPlan>(), n, has_p);
   HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1165,6 +1173,211 @@ int bpgpu_fold_points(int curve, const uint64_t* g_xyz, size_t n_out, const uint
   TRY(fold_points_launch(curve, d, d, s_lo, s_hi, d, d, s_lo, s_hi, 1, (uint32_t)n_out));
   TRY(points_out(curve, d, g_ctx.st_pts_in.as<uint32_t>(), n_out));
   HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_pts_in.p, n_out * 96, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+// ---- vector utilities of the k-ary protocols ----------------------------------
+extern "C++" {
+namespace {
+template <int SF>
+bool geometric_from_one(const uint64_t* y, size_t k) {
+  using HFs = host::HF<SF>;
+  host::H4 prev, r, cur;
+  memcpy(prev.v, y, 32);
+  if (!HFs::eq(prev, HFs::one())) return false;
+  memcpy(r.v, y + 4, 32);
+  prev = r;
+  for (size_t j = 2; j < k; j++) {
+    memcpy(cur.v, y + 4 * j, 32);
+    prev = HFs::mul(prev, r);
+    if (!HFs::eq(prev, cur)) return false;
+  }
+  return true;
+}
+
+int fold_scalars_kary_launch(int curve, const uint32_t* d_v, size_t ck, size_t k, const uint64_t* y, uint32_t* d_out) {
+  Ctx& C = g_ctx;
+  if (k > 1024) return fail(BPGPU_E_ARG, "k = %zu chunks: at most 1024 are supported", k);
+  if (ck == 0) return 0;
+  if (k == 0) {  // sum_vecs over no summands: vec![zero; len]
+    HIP_TRY(hipMemsetAsync(d_out, 0, ck * 32, C.stream));
+    return 0;
+  }
+  TRY(C.st_ip.ensure(k * 32));
+  HIP_TRY(hipMemcpyAsync(C.st_ip.p, y, k * 32, hipMemcpyHostToDevice, C.stream));
+  uint32_t gx = cdiv(ck, 256);
+  const uint32_t cap = (uint32_t)C.num_cus * 16;
+  if (gx > cap) gx = cap;
+  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
+  if (curve == BPGPU_PALLAS)
+    k_fold_scalars_kary<1><<<gx, 256, k * 36, C.stream>>>(d_v, C.st_ip.as<uint32_t>(), d_out, (uint32_t)ck, (uint32_t)k);
+  else
+    k_fold_scalars_kary<0><<<gx, 256, k * 36, C.stream>>>(d_v, C.st_ip.as<uint32_t>(), d_out, (uint32_t)ck, (uint32_t)k);
+  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// d_out[i] = sum_j y[j] d_g[j ck + i]; d_out (ck points) must not overlap d_g.  One shared-scalar
+// multiplication per chunk (k_fold_monic); when y = (1, r, r^2, ...) -- the only shape the reference
+// uses, powers(x, 0..k) -- Horner's rule needs k - 1 of them:  G_0 + r (G_1 + r (G_2 + ...)).
+int fold_points_kary_launch(int curve, const uint32_t* d_g, size_t ck, size_t k, const uint64_t* y, uint32_t* d_out) {
+  Ctx& C = g_ctx;
+  if (ck == 0) return 0;
+  if (k == 0) {
+    HIP_TRY(hipMemsetAsync(d_out, 0, ck * 64, C.stream));  // identity points
+    return 0;
+  }
+  const uint32_t n = (uint32_t)ck;
+  auto chunk = [&](size_t j) { return d_g + 16ull * j * ck; };
+  const bool geo = k >= 2 && (curve == BPGPU_PALLAS ? geometric_from_one<1>(y, k) : geometric_from_one<0>(y, k));
+  if (geo) {
+    const uint64_t* r = y + 4;
+    TRY(fold_monic_pq(curve, chunk(k - 2), chunk(k - 1), d_out, r, nullptr, nullptr, nullptr, r, 1, n, 1));
+    for (size_t j = k - 2; j-- > 0;) TRY(fold_monic_pq(curve, chunk(j), d_out, d_out, r, nullptr, nullptr, nullptr, r, 1, n, 1));
+    return 0;
+  }
+  TRY(fold_monic_pq(curve, d_out, chunk(k - 1), d_out, y + 4 * (k - 1), nullptr, nullptr, nullptr, y, 1, n, 0));
+  for (size_t j = k - 1; j-- > 0;)
+    TRY(fold_monic_pq(curve, d_out, chunk(j), d_out, y + 4 * j, nullptr, nullptr, nullptr, y, 1, n, 1));
+  return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int bpgpu_fold_scalars_kary_device(int curve, const void* d_v, size_t ck, size_t k, const uint64_t* y, void* d_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (ck > 0x7fffffffu || ck * (k ? k : 1) > 0xffffffffull) return fail(BPGPU_E_ARG, "vector too large");
+  if (ck && (!d_out || (k && (!d_v || !y)))) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(fold_scalars_kary_launch(curve, (const uint32_t*)d_v, ck, k, y, (uint32_t*)d_out));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_fold_scalars_kary(int curve, const uint64_t* v, size_t ck, size_t k, const uint64_t* y, uint64_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (ck > 0x7fffffffu || ck * (k ? k : 1) > 0x3fffffffull) return fail(BPGPU_E_ARG, "vector too large");
+  if (ck == 0) return 0;
+  if (!out || (k && (!v || !y))) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(g_ctx.st_sc.ensure((k ? k : 1) * ck * 32));
+  if (k) HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, v, k * ck * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  uint32_t* d = g_ctx.st_sc.as<uint32_t>();
+  TRY(fold_scalars_kary_launch(curve, d, ck, k, y, d));
+  HIP_TRY(hipMemcpyAsync(out, d, ck * 32, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_fold_points_kary_device(int curve, const void* d_g, size_t ck, size_t k, const uint64_t* y, void* d_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (ck > 0x7fffffffu || ck * (k ? k : 1) > 0x7fffffffull) return fail(BPGPU_E_ARG, "vector too large");
+  if (ck && (!d_out || (k && (!d_g || !y)))) return fail(BPGPU_E_ARG, "null pointer");
+  if (ck && k) {
+    const uint8_t *g0 = (const uint8_t*)d_g, *o0 = (const uint8_t*)d_out;
+    if (o0 < g0 + k * ck * 64 && g0 < o0 + ck * 64) return fail(BPGPU_E_ARG, "d_out overlaps d_g");
+  }
+  TRY(fold_points_kary_launch(curve, (const uint32_t*)d_g, ck, k, y, (uint32_t*)d_out));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_fold_points_kary(int curve, const uint64_t* g_xyz, size_t ck, size_t k, const uint64_t* y, uint64_t* out_xyz) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (ck > 0x7fffffffu || ck * (k ? k : 1) > 0x3fffffffull) return fail(BPGPU_E_ARG, "vector too large");
+  if (ck == 0) return 0;
+  if (!out_xyz || (k && (!g_xyz || !y))) return fail(BPGPU_E_ARG, "null pointer");
+  const size_t tot = k * ck;
+  TRY(g_ctx.st_pts_in.ensure((tot > ck ? tot : ck) * 96));
+  TRY(g_ctx.st_pts.ensure((tot + ck) * 64));
+  uint32_t* d = g_ctx.st_pts.as<uint32_t>();
+  uint32_t* d_o = d + 16ull * tot;
+  if (tot) {
+    HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, g_xyz, tot * 96, hipMemcpyHostToDevice, g_ctx.stream));
+    TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), d, tot, 0));
+  }
+  TRY(fold_points_kary_launch(curve, d, ck, k, y, d_o));
+  TRY(points_out(curve, d_o, g_ctx.st_pts_in.as<uint32_t>(), ck));
+  HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_pts_in.p, ck * 96, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_hadamard(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (n > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n == 0) return 0;
+  if (!a || !b || !out) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(g_ctx.st_sc.ensure(2 * n * 32));
+  uint32_t* d = g_ctx.st_sc.as<uint32_t>();
+  HIP_TRY(hipMemcpyAsync(d, a, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(d + 8ull * n, b, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  uint32_t gx = cdiv(n, 256);
+  const uint32_t cap = (uint32_t)g_ctx.num_cus * 16;
+  if (gx > cap) gx = cap;
+  if (curve == BPGPU_PALLAS)
+    k_hadamard<1><<<gx, 256, 0, g_ctx.stream>>>(d, d + 8ull * n, d, (uint32_t)n);
+  else
+    k_hadamard<0><<<gx, 256, 0, g_ctx.stream>>>(d, d + 8ull * n, d, (uint32_t)n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, d, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_hadamard_points(int curve, const uint64_t* bases_xyz, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (n > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n == 0) return 0;
+  if (!bases_xyz || !scalars || !out_xyz) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(g_ctx.st_pts_in.ensure(n * 96));
+  TRY(g_ctx.st_pts.ensure(n * 64));
+  TRY(g_ctx.st_sc.ensure(n * 32));
+  HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, bases_xyz, n * 96, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  uint32_t* d = g_ctx.st_pts.as<uint32_t>();
+  TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), d, n, 0));
+  if (curve == BPGPU_PALLAS)
+    k_hadamard_points<0><<<cdiv(n, 256), 256, 0, g_ctx.stream>>>(d, g_ctx.st_sc.as<uint32_t>(), d, (uint32_t)n);
+  else
+    k_hadamard_points<1><<<cdiv(n, 256), 256, 0, g_ctx.stream>>>(d, g_ctx.st_sc.as<uint32_t>(), d, (uint32_t)n);
+  HIP_TRY(hipGetLastError());
+  TRY(points_out(curve, d, g_ctx.st_pts_in.as<uint32_t>(), n));
+  HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_pts_in.p, n * 96, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+int bpgpu_powers(int curve, const uint64_t f[4], uint64_t start, size_t n, uint64_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (n > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
+  if (n == 0) return 0;
+  if (!f || !out) return fail(BPGPU_E_ARG, "null pointer");
+  TRY(g_ctx.st_sc.ensure(n * 32));
+  PowersArgs args;
+  memcpy(args.f, f, 32);
+  args.start = start;
+  const uint32_t lanes = cdiv(n, 8);
+  if (curve == BPGPU_PALLAS)
+    k_powers<1><<<cdiv(lanes, 256), 256, 0, g_ctx.stream>>>(args, g_ctx.st_sc.as<uint32_t>(), (uint32_t)n);
+  else
+    k_powers<0><<<cdiv(lanes, 256), 256, 0, g_ctx.stream>>>(args, g_ctx.st_sc.as<uint32_t>(), (uint32_t)n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, g_ctx.st_sc.p, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return 0;
 }

@@ -426,8 +426,11 @@ __device__ __forceinline__ Xyzz wave_sum_xyzz(Xyzz acc) {
 //   * chunks of 64 ordinary buckets, one per lane: chunk k is the (k / nbins)-th group of 64
 //     buckets, in decreasing size, of bin k % nbins (k_bin_offsets' order[]), so lanes of a wave
 //     walk lists of near-equal length and the kernel's tail is made of the shortest lists.
+#ifndef BP_ACCUM_WAVES
+#define BP_ACCUM_WAVES 2  // persistent waves per SIMD (tuning knob; also the launch bound)
+#endif
 template <int BF>
-__global__ void __launch_bounds__(256, 2) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
+__global__ void __launch_bounds__(256, BP_ACCUM_WAVES) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
                                                const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                uint32_t* __restrict__ bsum, uint32_t nbuckets, uint32_t nbins,
                                                int fine_bits, HeavyLists hv, uint32_t* __restrict__ work_counter) {
@@ -1086,9 +1089,11 @@ __device__ __forceinline__ Fe block_inverse_256(const Fe& v, uint32_t (*tree)[9]
   return ld(256 + tid);
 }
 
+// Vector y (blockIdx.y = 0 / 1):  o[i] = p[i] + s q[i]  (has_p)  or  s q[i]  (!has_p; p is not read).
+// o may alias p or q: a lane reads its own elements before it writes.
 template <int BF>
-__global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* __restrict__ g0, uint32_t* __restrict__ o0,
-                                                    const uint32_t* __restrict__ g1, uint32_t* __restrict__ o1,
+__global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const uint32_t* q0, uint32_t* o0,
+                                                    const uint32_t* p1, const uint32_t* q1, uint32_t* o1,
                                                     const MonicPlan* __restrict__ plans, uint32_t n, int has_p) {
   using F = Fp<BF>;
   using E = Ec<BF>;
@@ -1096,12 +1101,13 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* __restrict__
   __shared__ uint32_t tree[512][9];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
+  const uint32_t* gp = blockIdx.y == 0 ? p0 : p1;
+  const uint32_t* gq = blockIdx.y == 0 ? q0 : q1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
   const MonicPlan* f = plans + blockIdx.y;
   Xyzz acc = E::identity();
   if (active) {
-    Aff Q = IO::load_dev_affine(g + 16ull * (has_p ? i + n : i));
+    Aff Q = IO::load_dev_affine(gq + 16ull * i);
     if (!Q.inf) {
       // x never vanishes on a prime-order curve y^2 = x^3 + 5, so the three points are distinct
       const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
@@ -1120,7 +1126,7 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* __restrict__
         }
       }
     }
-    if (has_p) E::madd(acc, IO::load_dev_affine(g + 16ull * i));
+    if (has_p) E::madd(acc, IO::load_dev_affine(gp + 16ull * i));
   }
   // back to affine: x = X / ZZ, y = Y / ZZZ with one shared inversion of ZZ * ZZZ
   const bool fin = active && !acc.inf;
@@ -1152,6 +1158,134 @@ __global__ void __launch_bounds__(256) k_scale_scalars(const uint32_t* __restric
     uint4* po = reinterpret_cast<uint4*>(o + 8ull * i);
     po[0] = make_uint4(w[0], w[1], w[2], w[3]);
     po[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Vector utilities of the k-ary protocols: the generalised fold
+// sum_vecs(chunks.zip(y).map(scale_vec)) of bp_rec_kary.rs:100-112 == ipa_to_bp_unroll.rs:248-260,
+// hadamard / hadamard_gp / powers of src/util/mod.rs:57-85.  Scalars are in ark form.
+// ---------------------------------------------------------------------------
+// o[i] = sum_{j<k} y[j] v[j ck + i], i < ck.  y: k multipliers in device memory; their device form
+// is staged in LDS once per workgroup (dynamic LDS: 36 k bytes).  o may alias v.
+template <int SF>
+__global__ void __launch_bounds__(256) k_fold_scalars_kary(const uint32_t* v, const uint32_t* __restrict__ y, uint32_t* o,
+                                                           uint32_t ck, uint32_t k) {
+  using F = Fp<SF>;
+  extern __shared__ int32_t ysh[];
+  for (uint32_t j = threadIdx.x; j < k; j += blockDim.x) {
+    uint32_t w[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) w[t] = y[8ull * j + t];
+    const Fe m = F::load_ark(w);
+#pragma unroll
+    for (int t = 0; t < 9; t++) ysh[9 * j + t] = m.l[t];
+  }
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ck; i += gridDim.x * blockDim.x) {
+    Fe acc = F::zero();
+    for (uint32_t j = 0; j < k; j++) {
+      const uint4* pv = reinterpret_cast<const uint4*>(v + 8ull * ((uint64_t)j * ck + i));
+      uint4 a0 = pv[0], a1 = pv[1];
+      uint32_t w[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      Fe m;
+#pragma unroll
+      for (int t = 0; t < 9; t++) m.l[t] = ysh[9 * j + t];
+      acc = fe_partial_reduce<SF>(F::add(acc, F::mul(F::unpack(w), m)));
+    }
+    uint32_t w[8];
+    F::store_packed(acc, w);
+    uint4* po = reinterpret_cast<uint4*>(o + 8ull * i);
+    po[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    po[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
+// o[i] = a[i] b[i]  (hadamard, util/mod.rs:80-85); o may alias a or b
+template <int SF>
+__global__ void __launch_bounds__(256) k_hadamard(const uint32_t* a, const uint32_t* b, uint32_t* o, uint32_t n) {
+  using F = Fp<SF>;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint4* pa = reinterpret_cast<const uint4*>(a + 8ull * i);
+    const uint4* pb = reinterpret_cast<const uint4*>(b + 8ull * i);
+    uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+    uint32_t wa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    uint32_t wb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    // montmul(a 2^256, b 2^261) = ab 2^256: ark form again
+    uint32_t w[8];
+    F::store_packed(F::mul(F::unpack(wa), F::load_ark(wb)), w);
+    uint4* po = reinterpret_cast<uint4*>(o + 8ull * i);
+    po[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    po[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
+struct PowersArgs {
+  uint32_t f[8];  // ark form
+  uint64_t start;
+};
+// o[i] = f^(start + i)  (powers, util/mod.rs:57-64; f^0 = 1 also for f = 0, as Field::pow).  A lane
+// raises f to start + (its first index) by square-and-multiply and then walks its CHUNK consecutive
+// outputs with one multiplication each.
+template <int SF>
+__global__ void __launch_bounds__(256) k_powers(PowersArgs args, uint32_t* __restrict__ o, uint32_t n) {
+  using F = Fp<SF>;
+  constexpr uint32_t CHUNK = 8;
+  const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * CHUNK;
+  if (first >= n) return;
+  const Fe f = F::load_ark(args.f);
+  const uint64_t e = args.start + first;
+  Fe r = F::one();
+  for (int b = 63; b >= 0; b--) {
+    r = F::sqr(r);
+    if ((e >> b) & 1ull) r = F::mul(r, f);
+  }
+  for (uint32_t t = 0; t < CHUNK && first + t < n; t++) {
+    uint32_t w[8];
+    F::store_ark(r, w);
+    uint4* po = reinterpret_cast<uint4*>(o + 8ull * (first + t));
+    po[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    po[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    r = F::mul(r, f);
+  }
+}
+
+// o[i] = s[i] g[i]  (hadamard_gp, util/mod.rs:70-78: every lane has its own multiplier).  Plain
+// MSB-first double-and-add over the canonical scalar; the mixed add runs under the lanes' bit mask.
+// Back to affine with the workgroup-shared inversion.  o may alias g.
+template <int BF>
+__global__ void __launch_bounds__(256) k_hadamard_points(const uint32_t* g, const uint32_t* __restrict__ s, uint32_t* o,
+                                                         uint32_t n) {
+  using F = Fp<BF>;
+  using FS = Fp<1 - BF>;
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  __shared__ uint32_t tree[512][9];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n;
+  Xyzz acc = E::identity();
+  if (active) {
+    const Aff P = IO::load_dev_affine(g + 16ull * i);
+    uint32_t w[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) w[t] = s[8ull * i + t];
+    FS::pack(FS::canon(FS::mul(FS::unpack(w), FS::from_const(FS::C::C256TOCANON))), w);
+    if (!P.inf) {
+      for (int b = 254; b >= 0; b--) {
+        acc = E::dbl(acc);
+        if ((w[b >> 5] >> (b & 31)) & 1u) E::madd(acc, P);
+      }
+    }
+  }
+  const bool fin = active && !acc.inf;
+  const Fe den = fin ? F::mul(acc.zz, acc.zzz) : F::one();
+  const Fe inv = block_inverse_256<BF>(den, tree);
+  if (active) {
+    Aff r;
+    r.inf = !fin;
+    r.x = F::mul(acc.x, F::mul(inv, acc.zzz));
+    r.y = F::mul(acc.y, F::mul(inv, acc.zz));
+    IO::store_dev_affine(o + 16ull * i, r);
   }
 }
 

@@ -39,6 +39,13 @@ SIGNATURES = {
     "bpgpu_ip_device": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_fold_scalars_device": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bpgpu_fold_points_device": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "bpgpu_fold_scalars_kary": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "bpgpu_fold_points_kary": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "bpgpu_fold_scalars_kary_device": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "bpgpu_fold_points_kary_device": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "bpgpu_hadamard": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_hadamard_points": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_powers": (c_int, [c_int, c_void_p, c_uint64, c_size_t, c_void_p]),
     "bpgpu_ipa_begin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
     "bpgpu_ipa_begin_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
     "bpgpu_ipa_len": (c_size_t, [c_void_p]),
@@ -149,6 +156,59 @@ def fold_points(curve, g_xyz, s_lo, s_hi):
     n = len(g) // 2
     out = np.zeros((n, 12), dtype=np.uint64)
     _check(load().bpgpu_fold_points(curve, _ptr(g), n, _ptr(_u64(s_lo)), _ptr(_u64(s_hi)), _ptr(out)))
+    return out
+
+
+def fold_scalars_kary(curve, v, k, y):
+    """sum_vecs(chunks.zip(y).map(scale_vec)): out[i] = sum_j y[j] v[j*ck + i]."""
+    v, y = _u64(v, 4), _u64(y, 4)
+    assert len(y) == k and (k == 0 or len(v) % k == 0)
+    ck = len(v) // k if k else 0
+    out = np.zeros((ck, 4), dtype=np.uint64)
+    _check(load().bpgpu_fold_scalars_kary(curve, _ptr(v), ck, k, _ptr(y), _ptr(out)))
+    return out
+
+
+def fold_points_kary(curve, g_xyz, k, y):
+    g, y = _u64(g_xyz, 12), _u64(y, 4)
+    assert len(y) == k and (k == 0 or len(g) % k == 0)
+    ck = len(g) // k if k else 0
+    out = np.zeros((ck, 12), dtype=np.uint64)
+    _check(load().bpgpu_fold_points_kary(curve, _ptr(g), ck, k, _ptr(y), _ptr(out)))
+    return out
+
+
+def fold_scalars_kary_device(curve, d_v, ck, k, y, d_out):
+    _check(load().bpgpu_fold_scalars_kary_device(curve, d_v.ptr, ck, k, _ptr(_u64(y, 4)), d_out.ptr))
+
+
+def fold_points_kary_device(curve, d_g, ck, k, y, d_out):
+    _check(load().bpgpu_fold_points_kary_device(curve, d_g.ptr, ck, k, _ptr(_u64(y, 4)), d_out.ptr))
+
+
+def hadamard(curve, a, b):
+    a, b = _u64(a, 4), _u64(b, 4)
+    if len(a) != len(b):
+        raise AssertionError("hadamard: length mismatch")  # reference asserts (util/mod.rs:82)
+    out = np.zeros_like(a)
+    _check(load().bpgpu_hadamard(curve, _ptr(a), _ptr(b), len(a), _ptr(out)))
+    return out
+
+
+def hadamard_points(curve, bases_xyz, scalars):
+    g, s = _u64(bases_xyz, 12), _u64(scalars, 4)
+    if len(g) != len(s):
+        raise AssertionError("hadamard_gp: length mismatch")  # reference asserts (util/mod.rs:72)
+    out = np.zeros_like(g)
+    _check(load().bpgpu_hadamard_points(curve, _ptr(g), _ptr(s), len(g), _ptr(out)))
+    return out
+
+
+def powers(curve, f, start, end):
+    """powers(f, start..end), util/mod.rs:57-64."""
+    n = max(0, end - start)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    _check(load().bpgpu_powers(curve, _ptr(_u64(f)), start, n, _ptr(out)))
     return out
 
 

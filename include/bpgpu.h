@@ -107,6 +107,35 @@ int bpgpu_fold_scalars_device(int curve, const void* d_v, size_t n_out, const ui
 int bpgpu_fold_points_device(int curve, const void* d_g, size_t n_out, const uint64_t s_lo[4],
                              const uint64_t s_hi[4], void* d_out);
 
+/* ---- vector utilities of the k-ary protocols ("next" rows: bp_rec_kary, ipa_to_bp_unroll) ------
+ * Generalised fold: out[i] = sum_{j<k} y[j] * v[j*ck + i], i < ck.  Replaces
+ *   sum_vecs(chunks.iter().zip(&pows).map(|(c, y)| scale_vec(y, c)), ck_size)
+ * (scale_vec src/util/mod.rs:25-38, sum_vecs :40-55) at reference src/proofs/bp_rec_kary.rs:100-112,
+ * :171-178 and src/reductions/ipa_to_bp_unroll.rs:248-260, :352-359; the caller has already padded
+ * the vector to k*ck (zero_pad_to_multiple / zero_intersperse_to_multiple).  k = 1 is scale_vec,
+ * y = (1, ..., 1) is sum_vecs, k = 0 gives zeros / identities (sum_vecs of nothing).  y: k scalars,
+ * host memory.  Scalars: k <= 1024; `out` may alias `v`.  Points: jacobian in, jacobian Z = 1 out;
+ * when y = (1, r, r^2, ...) (the reference always passes powers(x, 0..k)) Horner's rule is used. */
+int bpgpu_fold_scalars_kary(int curve, const uint64_t* v, size_t ck, size_t k, const uint64_t* y,
+                            uint64_t* out);
+int bpgpu_fold_points_kary(int curve, const uint64_t* g_xyz, size_t ck, size_t k, const uint64_t* y,
+                           uint64_t* out_xyz);
+/* device-resident forms (dev affine points, ark scalars); d_out must not overlap d_g for points */
+int bpgpu_fold_scalars_kary_device(int curve, const void* d_v, size_t ck, size_t k, const uint64_t* y,
+                                   void* d_out);
+int bpgpu_fold_points_kary_device(int curve, const void* d_g, size_t ck, size_t k, const uint64_t* y,
+                                  void* d_out);
+/* out[i] = a[i] * b[i].  Replaces `hadamard`, reference src/util/mod.rs:80-85 (caller asserts
+ * equal length). */
+int bpgpu_hadamard(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+/* out[i] = bases[i] * scalars[i] (every element its own multiplier).  Replaces `hadamard_gp`,
+ * reference src/util/mod.rs:70-78 (used at src/reductions/com_r1cs_to_ipa.rs:110). */
+int bpgpu_hadamard_points(int curve, const uint64_t* bases_xyz, const uint64_t* scalars, size_t n,
+                          uint64_t* out_xyz);
+/* out[i] = f^(start + i), i < n.  Replaces `powers(f, start..start+n)`, reference
+ * src/util/mod.rs:57-64 (`neg_powers` = powers of the inverse, :66-68); f^0 = 1 for every f. */
+int bpgpu_powers(int curve, const uint64_t f[4], uint64_t start, size_t n, uint64_t* out);
+
 /* ---- device-resident IPA prover session -------------------------------------
  * Lets `Bp::prove` (reference src/proofs/bp_iter.rs:49-128) keep a, b, A, B in HBM
  * across its log2(N) rounds; Fiat-Shamir stays with the caller between

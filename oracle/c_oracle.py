@@ -164,3 +164,72 @@ def fs_challenge(curve, fs_seed, absorbed96: bytes):
     seed = np.frombuffer(fs_seed, dtype=np.uint8).copy()
     lib.po_fs_challenge(curve, _p(seed), _p(buf), ctypes.c_size_t(len(absorbed96) // 96), _p(o))
     return o
+
+
+# ---- vector utilities of the k-ary protocols (src/util/mod.rs:25-134) -------------------------
+def fold_scalars_kary(curve, v, k, y):
+    lib = load()
+    v, y = _u64(v, 4), _u64(y, 4)
+    ck = len(v) // k if k else 0
+    o = np.zeros((ck, 4), np.uint64)
+    lib.po_fold_scalars_kary(curve, _p(v), ctypes.c_size_t(ck), ctypes.c_size_t(k), _p(y), _p(o))
+    return o
+
+
+def fold_points_kary(curve, g_xyz, k, y, threads=1):
+    lib = load(threads)
+    g, y = _u64(g_xyz, 12), _u64(y, 4)
+    ck = len(g) // k if k else 0
+    o = np.zeros((ck, 12), np.uint64)
+    lib.po_fold_points_kary(curve, _p(g), ctypes.c_size_t(ck), ctypes.c_size_t(k), _p(y), _p(o))
+    return o
+
+
+def hadamard(curve, a, b):
+    lib = load()
+    a, b = _u64(a, 4), _u64(b, 4)
+    assert len(a) == len(b)
+    o = np.zeros_like(a)
+    lib.po_hadamard(curve, _p(a), _p(b), ctypes.c_size_t(len(a)), _p(o))
+    return o
+
+
+def hadamard_points(curve, bases_xyz, scalars, threads=1):
+    lib = load(threads)
+    g, s = _u64(bases_xyz, 12), _u64(scalars, 4)
+    assert len(g) == len(s)
+    o = np.zeros_like(g)
+    lib.po_hadamard_points(curve, _p(g), _p(s), ctypes.c_size_t(len(g)), _p(o))
+    return o
+
+
+def powers(curve, f, start, n):
+    lib = load()
+    o = np.zeros((n, 4), np.uint64)
+    lib.po_powers(curve, _p(_u64(f, 4)), ctypes.c_uint64(start), ctypes.c_size_t(n), _p(o))
+    return o
+
+
+def scalar_from_u64(curve, v):
+    lib = load()
+    o = np.zeros(4, np.uint64)
+    lib.po_scalar_from_u64(curve, ctypes.c_uint64(v), _p(o))
+    return o
+
+
+def _pad(fn, v, k):
+    v = _u64(v, 4)
+    fn.restype = ctypes.c_size_t
+    n = fn(_p(v), ctypes.c_size_t(len(v)), ctypes.c_size_t(k), None)
+    o = np.zeros((n, 4), np.uint64)
+    got = fn(_p(v), ctypes.c_size_t(len(v)), ctypes.c_size_t(k), _p(o))
+    assert got == n
+    return o
+
+
+def zero_pad_to_multiple(v, k):
+    return _pad(load().po_zero_pad_to_multiple, v, k)
+
+
+def zero_intersperse_to_multiple(v, k):
+    return _pad(load().po_zero_intersperse_to_multiple, v, k)

@@ -321,6 +321,74 @@ def fold_points(c: Curve, g: Sequence[Jac], s_lo: int, s_hi: int) -> List[Jac]:
 
 
 # ---------------------------------------------------------------------------
+# Vector utilities of the k-ary protocols (ref: src/util/mod.rs:25-134)
+# ---------------------------------------------------------------------------
+def powers(c: Curve, f: int, start: int, end: int) -> List[int]:
+    """ref: src/util/mod.rs:57-64 (range start..end)."""
+    out, cur = [], pow(f, start, c.r)
+    for _ in range(end - start):
+        out.append(cur)
+        cur = cur * f % c.r
+    return out
+
+
+def fold_scalars_kary(c: Curve, v: Sequence[int], k: int, y: Sequence[int]) -> List[int]:
+    """sum_vecs(chunks.zip(y).map(scale_vec))  (ref: src/proofs/bp_rec_kary.rs:100-104)."""
+    ck = len(v) // k if k else 0
+    return [sum(y[j] * v[j * ck + i] for j in range(k)) % c.r for i in range(ck)]
+
+
+def fold_points_kary(c: Curve, g: Sequence[Jac], k: int, y: Sequence[int]) -> List[Jac]:
+    """ref: src/proofs/bp_rec_kary.rs:105-112 (generators)."""
+    ck = len(g) // k if k else 0
+    out = []
+    for i in range(ck):
+        acc = to_jac(None)
+        for j in range(k):
+            acc = jac_add(c, acc, jac_mul(c, g[j * ck + i], y[j]))
+        out.append(acc)
+    return out
+
+
+def hadamard(c: Curve, a: Sequence[int], b: Sequence[int]) -> List[int]:
+    """ref: src/util/mod.rs:80-85."""
+    assert len(a) == len(b)
+    return [x * y % c.r for x, y in zip(a, b)]
+
+
+def hadamard_gp(c: Curve, bases: Sequence[Jac], scalars: Sequence[int]) -> List[Jac]:
+    """ref: src/util/mod.rs:70-78."""
+    assert len(bases) == len(scalars)
+    return [jac_mul(c, p, s) for p, s in zip(bases, scalars)]
+
+
+def zero_pad_to_multiple(v: Sequence, k: int, zero):
+    """ref: src/util/mod.rs:103-111."""
+    out = list(v)
+    want = ((len(out) - 1) // k + 1) * k
+    out.extend([zero] * (want - len(out)))
+    return out
+
+
+def zero_intersperse_to_multiple(v: Sequence, k: int, zero):
+    """ref: src/util/mod.rs:117-134."""
+    v = list(v)
+    block = (len(v) - 1) // k + 1
+    final = block * k
+    n_short = final - len(v)
+    out = []
+    for i in range(k):
+        if i >= k - n_short:
+            start = block * (k - n_short) + (block - 1) * (i + n_short - k)
+            out.extend(v[start:start + block - 1])
+            out.append(zero)
+        else:
+            out.extend(v[block * i:block * (i + 1)])
+    assert len(out) == final
+    return out
+
+
+# ---------------------------------------------------------------------------
 # ChaCha / rand_core BlockRng / ark_std::test_rng   [UPSTREAM-RECALLED]
 # ---------------------------------------------------------------------------
 def _rotl32(v: int, n: int) -> int:

@@ -10,6 +10,7 @@
  *   ip                   src/util/mod.rs:17-23
  *   scalar / generator fold, Bp::prove   src/proofs/bp_iter.rs:49-128
  *   msm_bench input recipe               examples/msm_bench.rs:40-44
+ *   scale_vec/sum_vecs k-ary folds, powers, hadamard, hadamard_gp, padding helpers   src/util/mod.rs:25-134
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
  * product (bulletproofs_amd + libbpgpu.so) never does.
  *
@@ -670,6 +671,122 @@ int po_normalise(int curve, const uint64_t* in_xyz, size_t n, uint64_t* out_xyz)
 int po_scalar_inverse(int curve, const uint64_t x[4], uint64_t out[4]) {
   fe_inv(&F[1 - curve], (fe*)out, (const fe*)x);
   return 0;
+}
+/* ---- vector utilities used by the k-ary protocols (src/util/mod.rs:25-85) ------------------------ */
+/* sum_vecs(chunks.zip(y).map(|(c, y)| scale_vec(y, c)), ck)  (src/proofs/bp_rec_kary.rs:100-104,
+ * src/reductions/ipa_to_bp_unroll.rs:248-252): out[i] = sum_j y[j] * v[j*ck + i], accumulated in
+ * the order of the fold (zero + term 0 + term 1 ...). */
+int po_fold_scalars_kary(int curve, const uint64_t* v, size_t ck, size_t k, const uint64_t* y, uint64_t* out) {
+  const field* f = &F[1 - curve];
+  const fe* vv = (const fe*)v;
+  const fe* yy = (const fe*)y;
+  for (size_t i = 0; i < ck; i++) {
+    fe acc = {{0, 0, 0, 0}};
+    for (size_t j = 0; j < k; j++) {
+      fe t;
+      fe_mul(f, &t, &vv[j * ck + i], &yy[j]);
+      fe_add(f, &acc, &acc, &t);
+    }
+    ((fe*)out)[i] = acc;
+  }
+  return 0;
+}
+/* same for generators (bp_rec_kary.rs:105-112, ipa_to_bp_unroll.rs:253-260): scale_vec on a
+ * Vec<G> is `c *= s`, i.e. Group::mul; outputs normalised. */
+typedef struct { const field* f; const jac* g; jac* out; size_t ck, k; const uint64_t (*yc)[4]; } kfold_ctx;
+static void kfold_job(void* vc, int idx) {
+  kfold_ctx* c = (kfold_ctx*)vc;
+  size_t lo = (size_t)idx * 16, hi = lo + 16;
+  if (hi > c->ck) hi = c->ck;
+  for (size_t i = lo; i < hi; i++) {
+    jac acc, t, u;
+    jac_set_inf(c->f, &acc);
+    for (size_t j = 0; j < c->k; j++) {
+      jac_mul(c->f, &t, &c->g[j * c->ck + i], c->yc[j]);
+      jac_add(c->f, &u, &acc, &t);
+      acc = u;
+    }
+    jac_normalise(c->f, &c->out[i], &acc);
+  }
+}
+int po_fold_points_kary(int curve, const uint64_t* g_xyz, size_t ck, size_t k, const uint64_t* y, uint64_t* out_xyz) {
+  uint64_t (*yc)[4] = malloc((k ? k : 1) * 32);
+  for (size_t j = 0; j < k; j++) fe_to_canon(&F[1 - curve], yc[j], (const fe*)y + j);
+  kfold_ctx c = {&F[curve], (const jac*)g_xyz, (jac*)out_xyz, ck, k, (const uint64_t(*)[4])yc};
+  run_jobs(kfold_job, &c, (int)((ck + 15) / 16));
+  free(yc);
+  return 0;
+}
+/* hadamard, src/util/mod.rs:80-85 */
+int po_hadamard(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  for (size_t i = 0; i < n; i++) fe_mul(&F[1 - curve], (fe*)out + i, (const fe*)a + i, (const fe*)b + i);
+  return 0;
+}
+/* hadamard_gp, src/util/mod.rs:70-78: out[i] = bases[i].mul(scalars[i]); outputs normalised */
+typedef struct { const field* f; const field* fs; const jac* g; const fe* s; jac* out; size_t n; } hgp_ctx;
+static void hgp_job(void* vc, int idx) {
+  hgp_ctx* c = (hgp_ctx*)vc;
+  size_t lo = (size_t)idx * 16, hi = lo + 16;
+  if (hi > c->n) hi = c->n;
+  for (size_t i = lo; i < hi; i++) {
+    uint64_t k[4];
+    jac t;
+    fe_to_canon(c->fs, k, &c->s[i]);
+    jac_mul(c->f, &t, &c->g[i], k);
+    jac_normalise(c->f, &c->out[i], &t);
+  }
+}
+int po_hadamard_points(int curve, const uint64_t* bases_xyz, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
+  hgp_ctx c = {&F[curve], &F[1 - curve], (const jac*)bases_xyz, (const fe*)scalars, (jac*)out_xyz, n};
+  run_jobs(hgp_job, &c, (int)((n + 15) / 16));
+  return 0;
+}
+/* powers, src/util/mod.rs:57-64: first = f.pow([start]); successors multiply by f */
+int po_powers(int curve, const uint64_t f_in[4], uint64_t start, size_t n, uint64_t* out) {
+  const field* f = &F[1 - curve];
+  const uint64_t e[4] = {start, 0, 0, 0};
+  fe cur;
+  fe_pow(f, &cur, (const fe*)f_in, e);
+  for (size_t i = 0; i < n; i++) {
+    ((fe*)out)[i] = cur;
+    fe nx;
+    fe_mul(f, &nx, &cur, (const fe*)f_in);
+    cur = nx;
+  }
+  return 0;
+}
+/* Fr::from(u64) in ark memory form (used by the padding-helper known answers, util/mod.rs:146-203) */
+int po_scalar_from_u64(int curve, uint64_t v, uint64_t out[4]) {
+  const uint64_t c[4] = {v, 0, 0, 0};
+  fe_from_canon(&F[1 - curve], (fe*)out, c);
+  return 0;
+}
+/* zero_pad_to_multiple (util/mod.rs:103-111) and zero_intersperse_to_multiple (:117-134) on 32-byte
+ * elements; return the output length (out may be NULL to query it). */
+size_t po_zero_pad_to_multiple(const uint64_t* in, size_t n, size_t k, uint64_t* out) {
+  size_t chunk = (n - 1) / k + 1, want = chunk * k;
+  if (out) {
+    memcpy(out, in, n * 32);
+    if (want > n) memset(out + 4 * n, 0, (want - n) * 32);
+  }
+  return want > n ? want : n;
+}
+size_t po_zero_intersperse_to_multiple(const uint64_t* in, size_t n, size_t k, uint64_t* out) {
+  size_t block = (n - 1) / k + 1, fin = block * k, nshort = fin - n, o = 0;
+  if (!out) return fin;
+  for (size_t i = 0; i < k; i++) {
+    if (i >= k - nshort) {
+      size_t start = block * (k - nshort) + (block - 1) * (i + nshort - k);
+      memcpy(out + 4 * o, in + 4 * start, (block - 1) * 32);
+      o += block - 1;
+      memset(out + 4 * o, 0, 32);
+      o += 1;
+    } else {
+      memcpy(out + 4 * o, in + 4 * block * i, block * 32);
+      o += block;
+    }
+  }
+  return o;
 }
 /* on-curve check of a Jacobian point: Y^2 = X^3 + 5 Z^6 */
 int po_on_curve(int curve, const uint64_t* p_xyz) {

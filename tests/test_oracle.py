@@ -188,3 +188,59 @@ def test_2ary_step_invariant():
 def test_zero_pad_to_two_power():
     # src/util/mod.rs:137-144
     assert [len(pm.zero_pad_to_two_power([1] * n, 0)) for n in (0, 1, 2, 3, 4, 5, 17)] == [1, 1, 2, 4, 4, 8, 32]
+
+
+# ---- vector utilities of the k-ary protocols (src/util/mod.rs:25-134) --------------------------
+# The reference's own exact-value tests (src/util/mod.rs:154-201, Pallas Fr): the only known answers
+# it holds anywhere near this path.
+REF_INTERSPERSE = [
+    ([1, 2, 3, 4], 3, [1, 2, 3, 0, 4, 0]),        # zero_intersperse_max_fill
+    ([1, 2, 3, 4, 5, 6], 3, [1, 2, 3, 4, 5, 6]),  # zero_intersperse_full
+    ([1, 2, 3, 4, 5], 3, [1, 2, 3, 4, 5, 0]),     # zero_intersperse_one_short
+]
+
+
+@pytest.mark.parametrize("xs,k,want", REF_INTERSPERSE)
+def test_zero_intersperse_reference_known_answers(xs, k, want):
+    assert pm.zero_intersperse_to_multiple(xs, k, 0) == want
+    fr = lambda v: co.scalar_from_u64(0, v)  # noqa: E731  Fr::from(u32) in ark memory form
+    got = co.zero_intersperse_to_multiple(np.stack([fr(x) for x in xs]), k)
+    assert (got == np.stack([fr(w) for w in want])).all()
+    # Fr::from agrees between the oracles
+    assert (fr(5) == H.scalar_abi(pm.PALLAS, 5)).all()
+
+
+def test_zero_pad_to_multiple():
+    for n, k in [(1, 3), (3, 3), (4, 3), (7, 4), (8, 4), (5, 8)]:
+        want = pm.zero_pad_to_multiple(list(range(1, n + 1)), k, 0)
+        assert len(want) % k == 0 and len(want) - n < k
+        got = co.zero_pad_to_multiple(H.scalars_abi(pm.PALLAS, list(range(1, n + 1))), k)
+        assert H.scalars_from_abi(pm.PALLAS, got) == want
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_kary_utilities_c_vs_model(c):
+    cid = c.curve_id
+    x = H.rand_scalars(c, 1, 501)[0]
+    for k, ck in [(1, 3), (2, 4), (3, 2), (5, 3)]:
+        v = H.rand_scalars(c, k * ck, 502 + k)
+        v[0] = 0
+        y = pm.powers(c, x, 0, k) if k != 3 else H.rand_scalars(c, k, 77)
+        assert H.scalars_from_abi(c, co.powers(cid, H.scalar_abi(c, x), 0, k)) == pm.powers(c, x, 0, k)
+        want = pm.fold_scalars_kary(c, v, k, y)
+        got = co.fold_scalars_kary(cid, H.scalars_abi(c, v), k, H.scalars_abi(c, y))
+        assert H.scalars_from_abi(c, got) == want
+        g = H.rand_points(c, k * ck, 503 + k)
+        g[1] = None
+        wantp = [pm.jac_to_affine(c, p) for p in pm.fold_points_kary(c, [pm.to_jac(p) for p in g], k, y)]
+        gotp = co.fold_points_kary(cid, H.jac_abi(c, g), k, H.scalars_abi(c, y))
+        assert H.jac_from_abi(c, gotp) == wantp
+    assert H.scalars_from_abi(c, co.powers(cid, H.scalar_abi(c, x), 3, 4)) == pm.powers(c, x, 3, 7)
+    assert H.scalars_from_abi(c, co.powers(cid, H.scalar_abi(c, 0), 0, 3)) == [1, 0, 0]   # 0^0 = 1 (Field::pow)
+    a, b = H.rand_scalars(c, 6, 504), H.rand_scalars(c, 6, 505)
+    assert H.scalars_from_abi(c, co.hadamard(cid, H.scalars_abi(c, a), H.scalars_abi(c, b))) == pm.hadamard(c, a, b)
+    g = H.rand_points(c, 6, 506)
+    g[2] = None
+    a[3] = 0
+    want = [pm.jac_to_affine(c, p) for p in pm.hadamard_gp(c, [pm.to_jac(p) for p in g], a)]
+    assert H.jac_from_abi(c, co.hadamard_points(cid, H.jac_abi(c, g), H.scalars_abi(c, a))) == want
