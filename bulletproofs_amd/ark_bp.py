@@ -166,3 +166,52 @@ def scalar_inverse(curve, x):
     out = np.zeros(4, np.uint64)
     _check(load().arkbp_scalar_inverse(curve, _p(_u64(x, 4)), _p(out)))
     return out
+
+
+def ipa_check(curve, a_gens, b_gens, ip_gen, result, a, b):
+    """IpaRelation::check (ipa.rs:134-146): raises Panic where the reference's assert fails."""
+    A, B, q, res = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(result, 12)
+    a, b = _u64(a, 4), _u64(b, 4)
+    _check(load().arkbp_ipa_check(curve, _p(A), _p(B), _p(q), _p(res), _p(a), _p(b), c_size_t(len(a))))
+
+
+def kary_prove_step(curve, k, a_gens, b_gens, ip_gen, result, a, b, fs_seed: bytes):
+    """KaryBp prove_step (bp_rec_kary.rs:27-143) -> dict(pos_cross, neg_cross, a_gens, b_gens, a, b, result)."""
+    A, B, q, res = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(result, 12)
+    a, b = _u64(a, 4), _u64(b, 4)
+    n = len(a)
+    ck = (n - 1) // k + 1
+    pos, neg = np.zeros((max(k - 1, 1), 12), np.uint64), np.zeros((max(k - 1, 1), 12), np.uint64)
+    A2, B2 = np.zeros((ck, 12), np.uint64), np.zeros((ck, 12), np.uint64)
+    a2, b2 = np.zeros((ck, 4), np.uint64), np.zeros((ck, 4), np.uint64)
+    r2 = np.zeros(12, np.uint64)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    m = _check(load().arkbp_kary_prove_step(curve, c_size_t(k), _p(A), _p(B), _p(q), _p(res), _p(a), _p(b), c_size_t(n),
+                                            _p(seed), _p(pos), _p(neg), _p(A2), _p(B2), _p(a2), _p(b2), _p(r2)))
+    assert m == ck
+    return dict(pos_cross=pos[:k - 1], neg_cross=neg[:k - 1], a_gens=A2, b_gens=B2, a=a2, b=b2, result=r2)
+
+
+def kary_verify_step(curve, k, a_gens, b_gens, ip_gen, result, pos_cross, neg_cross, fs_seed: bytes):
+    A, B, q, res = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(result, 12)
+    pos, neg = _u64(pos_cross, 12), _u64(neg_cross, 12)
+    n = len(A)
+    ck = (n - 1) // k + 1
+    A2, B2 = np.zeros((ck, 12), np.uint64), np.zeros((ck, 12), np.uint64)
+    r2 = np.zeros(12, np.uint64)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    m = _check(load().arkbp_kary_verify_step(curve, c_size_t(k), _p(A), _p(B), _p(q), _p(res), c_size_t(n),
+                                             _p(pos) if len(pos) else None, _p(neg) if len(neg) else None, _p(seed),
+                                             _p(A2), _p(B2), _p(r2)))
+    assert m == ck
+    return dict(a_gens=A2, b_gens=B2, result=r2)
+
+
+def pad(mode, v, k):
+    """util::zero_pad_to_multiple (mode 0) / zero_intersperse_to_multiple (mode 1) on scalars; pure host code."""
+    v = _u64(v, 4)
+    out = np.zeros((len(v) + k + 1, 4), np.uint64)
+    lib = load()
+    lib.arkbp_pad.restype = ctypes.c_long
+    m = _check(lib.arkbp_pad(mode, _p(v), c_size_t(len(v)), c_size_t(k), _p(out)))
+    return out[:m]

@@ -9,6 +9,9 @@
 //   IpaGens / IpaInstance / IpaWitness / IpaRelation       src/relations/ipa.rs:10-160
 //   Bp::{prove, verify}, BpProof                           src/proofs/bp_iter.rs:24-197
 //   Bp2aryStep::{prove, verify}                            src/reductions/bp_2ary_step.rs:19-142
+//   util::{powers, scale_vec, sum_vecs, hadamard, hadamard_gp, zero_pad_to_multiple,
+//          zero_intersperse_to_multiple}                    src/util/mod.rs:25-134
+//   KaryBp::{prove_step, verify_step}                      src/proofs/bp_rec_kary.rs:27-190
 #pragma once
 #include <array>
 #include <cstdint>
@@ -291,6 +294,107 @@ std::vector<Z> zero_pad_to_two_power(const std::vector<Z>& v, const Z& zero) {  
   out.resize(next_power_of_two(v.size()), zero);
   return out;
 }
+// util/mod.rs:103-111 (like the reference, undefined for an empty array: (len - 1) underflows there)
+template <class Z>
+std::vector<Z> zero_pad_to_multiple(const std::vector<Z>& v, size_t k, const Z& zero) {
+  if (v.empty() || k == 0) throw Panic("attempt to subtract with overflow / divide by zero");
+  std::vector<Z> out(v);
+  const size_t want = ((v.size() - 1) / k + 1) * k;
+  if (want > out.size()) out.resize(want, zero);
+  return out;
+}
+// util/mod.rs:117-134
+template <class Z>
+std::vector<Z> zero_intersperse_to_multiple(const std::vector<Z>& v, size_t k, const Z& zero) {
+  if (v.empty() || k == 0) throw Panic("attempt to subtract with overflow / divide by zero");
+  const size_t block = (v.size() - 1) / k + 1, fin = block * k, n_short = fin - v.size();
+  std::vector<Z> out;
+  out.reserve(fin);
+  for (size_t i = 0; i < k; i++) {
+    if (i >= k - n_short) {
+      const size_t start = block * (k - n_short) + (block - 1) * (i + n_short - k);
+      out.insert(out.end(), v.begin() + start, v.begin() + start + block - 1);
+      out.push_back(zero);
+    } else {
+      out.insert(out.end(), v.begin() + block * i, v.begin() + block * (i + 1));
+    }
+  }
+  if (out.size() != fin) throw Panic("assertion failed: `(left == right)` in zero_intersperse_to_multiple");
+  return out;
+}
+// powers(f, start..end), util/mod.rs:57-64
+template <int CURVE>
+std::vector<Fr> powers(const Fr& f, size_t start, size_t end) {
+  std::vector<Fr> out(end > start ? end - start : 0);
+  check(bpgpu_powers(CURVE, f.v, start, out.size(), out.empty() ? nullptr : out.data()->v));
+  return out;
+}
+template <int CURVE>
+std::vector<Fr> neg_powers(const Fr& f, size_t start, size_t end) {  // util/mod.rs:66-68
+  return powers<CURVE>(ScalarOps<CURVE>::inverse(f), start, end);
+}
+// The k-ary fold  sum_vecs(chunks.zip(y).map(|(c, y)| scale_vec(y, c)), ck)  in one call
+// (bp_rec_kary.rs:100-112): v holds the k chunks back to back.
+template <int CURVE>
+std::vector<Fr> fold_chunks(const std::vector<Fr>& v, size_t k, const std::vector<Fr>& y) {
+  if (y.size() < k || (k && v.size() % k)) throw Panic("assertion failed: `(left == right)` (summand.len(), len)");
+  std::vector<Fr> out(k ? v.size() / k : 0);
+  check(bpgpu_fold_scalars_kary(CURVE, v.empty() ? nullptr : v.data()->v, out.size(), k, k ? y.data()->v : nullptr,
+                                out.empty() ? nullptr : out.data()->v));
+  return out;
+}
+template <int CURVE>
+std::vector<G> fold_chunks(const std::vector<G>& v, size_t k, const std::vector<Fr>& y) {
+  if (y.size() < k || (k && v.size() % k)) throw Panic("assertion failed: `(left == right)` (summand.len(), len)");
+  std::vector<G> out(k ? v.size() / k : 0);
+  check(bpgpu_fold_points_kary(CURVE, v.empty() ? nullptr : v.data()->v, out.size(), k, k ? y.data()->v : nullptr,
+                               out.empty() ? nullptr : out.data()->v));
+  return out;
+}
+// scale_vec (util/mod.rs:25-38) and sum_vecs (:40-55) on their own: the fold with one chunk, and the
+// fold with every multiplier one
+template <int CURVE, class Z>
+std::vector<Z> scale_vec(const Fr& s, const std::vector<Z>& b) {
+  return fold_chunks<CURVE>(b, 1, std::vector<Fr>{s});
+}
+template <int CURVE, class Z>
+std::vector<Z> sum_vecs(const std::vector<std::vector<Z>>& vs, size_t len, const Z& zero) {
+  std::vector<Z> flat;
+  for (const auto& v : vs) {
+    if (v.size() != len) throw Panic("assertion failed: `(left == right)` (summand.len(), len)");
+    flat.insert(flat.end(), v.begin(), v.end());
+  }
+  if (vs.empty()) return std::vector<Z>(len, zero);  // vec![F::zero(); len]
+  return fold_chunks<CURVE>(flat, vs.size(), std::vector<Fr>(vs.size(), ScalarOps<CURVE>::one()));
+}
+template <int CURVE>
+std::vector<Fr> hadamard(const std::vector<Fr>& a, const std::vector<Fr>& b) {  // util/mod.rs:80-85
+  if (a.size() != b.size()) throw Panic("assertion failed: `(left == right)` (a.len(), b.len())");
+  std::vector<Fr> out(a.size());
+  check(bpgpu_hadamard(CURVE, a.empty() ? nullptr : a.data()->v, b.empty() ? nullptr : b.data()->v, a.size(),
+                       out.empty() ? nullptr : out.data()->v));
+  return out;
+}
+template <int CURVE>
+std::vector<G> hadamard_gp(const std::vector<G>& bases, const std::vector<Fr>& scalars) {  // util/mod.rs:70-78
+  if (bases.size() != scalars.size()) throw Panic("assertion failed: `(left == right)` (bases.len(), scalars.len())");
+  std::vector<G> out(bases.size());
+  check(bpgpu_hadamard_points(CURVE, bases.empty() ? nullptr : bases.data()->v, scalars.empty() ? nullptr : scalars.data()->v,
+                              bases.size(), out.empty() ? nullptr : out.data()->v));
+  return out;
+}
+// sum of group elements (Iterator::sum over G), through the library's point adder
+template <int CURVE>
+G sum_points(const std::vector<G>& v) {
+  std::vector<uint64_t> xy(9 * (v.size() ? v.size() : 1), 0);
+  for (size_t i = 0; i < v.size(); i++) {
+    const bool inf = (v[i].v[8] | v[i].v[9] | v[i].v[10] | v[i].v[11]) == 0;
+    if (inf) xy[9 * i + 8] = 1; else std::memcpy(&xy[9 * i], v[i].v, 64);  // inputs are normalised (Z = 1)
+  }
+  uint64_t out[9];
+  check(bpgpu_points_sum(CURVE, xy.data(), v.size(), out));
+  return PointOps<CURVE>::from_xy_inf(out);
+}
 }  // namespace util
 
 // ---- relations (src/relations/ipa.rs) ---------------------------------------------------------
@@ -545,6 +649,96 @@ struct Bp2aryStep {
     check(bpgpu_fold_points(CURVE, a_gen.data()->v, n, x_inv.v, x.v, next.gens.a_gens.data()->v));
     check(bpgpu_fold_points(CURVE, b_gen.data()->v, n, x.v, x_inv.v, next.gens.b_gens.data()->v));
     next.result = p_next(proof.l, proof.r, instance.result, x, x_inv);
+    return next;
+  }
+};
+
+// ---- proofs::bp_rec_kary (src/proofs/bp_rec_kary.rs): one k-ary round ---------------------------
+template <int CURVE>
+struct KaryBp {
+  using S = ScalarOps<CURVE>;
+  using P = PointOps<CURVE>;
+  struct StepOut {
+    IpaInstance instance;
+    IpaWitness witness;
+    std::vector<G> pos_cross, neg_cross;
+  };
+  static void absorb_vec(FiatShamirRng& fs, const std::vector<G>& v) {  // ToBytes for Vec<G>: elements back to back
+    std::vector<uint8_t> bytes(96 * v.size());
+    for (size_t i = 0; i < v.size(); i++) P::to_bytes(v[i], bytes.data() + 96 * i);
+    fs.absorb(bytes.data(), bytes.size());
+  }
+  // p_next = msm(pos | neg, x_pows[1..] | x_inv_pows[1..]) + p   (:113-116, :179-182)
+  static G p_next(const std::vector<G>& pos, const std::vector<G>& neg, const std::vector<Fr>& xp,
+                  const std::vector<Fr>& xip, const G& p) {
+    std::vector<G> pts(pos);
+    pts.insert(pts.end(), neg.begin(), neg.end());
+    std::vector<Fr> sc(xp.begin() + 1, xp.end());
+    sc.insert(sc.end(), xip.begin() + 1, xip.end());
+    pts.push_back(p);
+    sc.push_back(S::one());
+    return util::msm<CURVE>(pts, sc);
+  }
+  // prove_step, :27-143
+  static StepOut prove_step(size_t k, const IpaInstance& instance, const IpaWitness& witness, FiatShamirRng& fs) {
+    Fr zero{};
+    std::vector<Fr> a = util::zero_pad_to_multiple(witness.a, k, zero), b = util::zero_pad_to_multiple(witness.b, k, zero);
+    std::vector<G> a_gen = util::zero_pad_to_multiple(instance.gens.a_gens, k, zero_point<CURVE>());
+    std::vector<G> b_gen = util::zero_pad_to_multiple(instance.gens.b_gens, k, zero_point<CURVE>());
+    if (b.size() != a.size() || a_gen.size() != a.size() || b_gen.size() != a.size()) throw Panic("assertion failed: vector sizes");
+    const size_t ck = a.size() / k;
+    const G& q = instance.gens.ip_gen;
+    // X[i, j] = a[i] * A[j] + b[j] * B[i] + <a[i], b[j]> * Q   (:52-60)
+    auto x = [&](size_t i, size_t j) {
+      std::vector<G> pts(a_gen.begin() + j * ck, a_gen.begin() + (j + 1) * ck);
+      pts.insert(pts.end(), b_gen.begin() + i * ck, b_gen.begin() + (i + 1) * ck);
+      pts.push_back(q);
+      std::vector<Fr> sc(a.begin() + i * ck, a.begin() + (i + 1) * ck);
+      sc.insert(sc.end(), b.begin() + j * ck, b.begin() + (j + 1) * ck);
+      sc.push_back(util::ip<CURVE>(a.data() + i * ck, ck, b.data() + j * ck, ck));
+      return util::msm<CURVE>(pts, sc);
+    };
+    StepOut out;
+    for (size_t i = 0; i + 1 < k; i++) {  // :64-70
+      std::vector<G> xs;
+      for (size_t j = 0; j < k - i - 1; j++) xs.push_back(x(i + j + 1, j));
+      out.pos_cross.push_back(util::sum_points<CURVE>(xs));
+    }
+    for (size_t i = 0; i + 1 < k; i++) {  // :74-76
+      std::vector<G> xs;
+      for (size_t j = 0; j < k - i - 1; j++) xs.push_back(x(j, i + j + 1));
+      out.neg_cross.push_back(util::sum_points<CURVE>(xs));
+    }
+    absorb_vec(fs, out.pos_cross);
+    absorb_vec(fs, out.neg_cross);
+    const Fr xc = fs.rand_scalar<CURVE>(), x_inv = S::inverse(xc);
+    const std::vector<Fr> x_pows = util::powers<CURVE>(xc, 0, k), x_inv_pows = util::powers<CURVE>(x_inv, 0, k);
+    out.witness.a = util::fold_chunks<CURVE>(a, k, x_pows);               // :100
+    out.witness.b = util::fold_chunks<CURVE>(b, k, x_inv_pows);           // :101-104
+    out.instance.gens.a_gens = util::fold_chunks<CURVE>(a_gen, k, x_inv_pows);  // :105-108
+    out.instance.gens.b_gens = util::fold_chunks<CURVE>(b_gen, k, x_pows);      // :109-112
+    out.instance.gens.vec_size = ck;
+    out.instance.gens.ip_gen = q;
+    out.instance.result = p_next(out.pos_cross, out.neg_cross, x_pows, x_inv_pows, instance.result);
+    return out;
+  }
+  // verify_step, :145-190
+  static IpaInstance verify_step(size_t k, const IpaInstance& instance, const std::vector<G>& pos_cross,
+                                 const std::vector<G>& neg_cross, FiatShamirRng& fs) {
+    std::vector<G> a_gen = util::zero_pad_to_multiple(instance.gens.a_gens, k, zero_point<CURVE>());
+    std::vector<G> b_gen = util::zero_pad_to_multiple(instance.gens.b_gens, k, zero_point<CURVE>());
+    if (pos_cross.size() + 1 != k || neg_cross.size() + 1 != k) throw Panic("assertion failed: cross-term count");
+    const size_t ck = a_gen.size() / k;
+    absorb_vec(fs, pos_cross);
+    absorb_vec(fs, neg_cross);
+    const Fr xc = fs.rand_scalar<CURVE>(), x_inv = S::inverse(xc);
+    const std::vector<Fr> x_pows = util::powers<CURVE>(xc, 0, k), x_inv_pows = util::powers<CURVE>(x_inv, 0, k);
+    IpaInstance next;
+    next.gens.vec_size = ck;
+    next.gens.ip_gen = instance.gens.ip_gen;
+    next.gens.a_gens = util::fold_chunks<CURVE>(a_gen, k, x_inv_pows);
+    next.gens.b_gens = util::fold_chunks<CURVE>(b_gen, k, x_pows);
+    next.result = p_next(pos_cross, neg_cross, x_pows, x_inv_pows, instance.result);
     return next;
   }
 };

@@ -151,6 +151,47 @@ int step_verify(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* 
   std::memcpy(result_next, nx.result.v, 96);
   return (int)m;
 }
+
+// KaryBp::prove_step; cross terms: (k - 1) points each; next vectors: ck = ceil(n / k) elements each
+template <int CURVE>
+int kary_prove_step(size_t k, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result,
+                    const uint64_t* a, const uint64_t* b, size_t n, const uint8_t* fs_seed, uint64_t* pos_cross,
+                    uint64_t* neg_cross, uint64_t* a_gens_next, uint64_t* b_gens_next, uint64_t* a_next, uint64_t* b_next,
+                    uint64_t* result_next) {
+  IpaInstance x = make_instance(a_gens, b_gens, ip_gen, result, n);
+  IpaWitness w = make_witness(a, b, n);
+  FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
+  auto o = KaryBp<CURVE>::prove_step(k, x, w, fs);
+  const size_t m = o.witness.a.size();
+  if (k > 1) {
+    std::memcpy(pos_cross, o.pos_cross.data(), (k - 1) * 96);
+    std::memcpy(neg_cross, o.neg_cross.data(), (k - 1) * 96);
+  }
+  std::memcpy(a_gens_next, o.instance.gens.a_gens.data(), m * 96);
+  std::memcpy(b_gens_next, o.instance.gens.b_gens.data(), m * 96);
+  std::memcpy(a_next, o.witness.a.data(), m * 32);
+  std::memcpy(b_next, o.witness.b.data(), m * 32);
+  std::memcpy(result_next, o.instance.result.v, 96);
+  return (int)m;
+}
+template <int CURVE>
+int kary_verify_step(size_t k, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result,
+                     size_t n, const uint64_t* pos_cross, const uint64_t* neg_cross, const uint8_t* fs_seed,
+                     uint64_t* a_gens_next, uint64_t* b_gens_next, uint64_t* result_next) {
+  IpaInstance x = make_instance(a_gens, b_gens, ip_gen, result, n);
+  std::vector<G> pos(k - 1), neg(k - 1);
+  if (k > 1) {
+    std::memcpy(pos.data(), pos_cross, (k - 1) * 96);
+    std::memcpy(neg.data(), neg_cross, (k - 1) * 96);
+  }
+  FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
+  IpaInstance nx = KaryBp<CURVE>::verify_step(k, x, pos, neg, fs);
+  const size_t m = nx.gens.a_gens.size();
+  std::memcpy(a_gens_next, nx.gens.a_gens.data(), m * 96);
+  std::memcpy(b_gens_next, nx.gens.b_gens.data(), m * 96);
+  std::memcpy(result_next, nx.result.v, 96);
+  return (int)m;
+}
 }  // namespace
 
 #define BY_CURVE(fn, ...) (curve == 0 ? fn<0>(__VA_ARGS__) : fn<1>(__VA_ARGS__))
@@ -254,6 +295,46 @@ int arkbp_scalar_inverse(int curve, const uint64_t* x, uint64_t* out) {
     Fr r = curve == 0 ? ScalarOps<0>::inverse(a) : ScalarOps<1>::inverse(a);
     std::memcpy(out, r.v, 32);
     return 0;
+  });
+}
+// IpaRelation::check (ipa.rs:134-146): 0 = holds, -100 = the reference would have panicked
+int arkbp_ipa_check(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result,
+                    const uint64_t* a, const uint64_t* b, size_t n) {
+  return guarded([&] {
+    IpaInstance x = make_instance(a_gens, b_gens, ip_gen, result, n);
+    IpaWitness w = make_witness(a, b, n);
+    if (curve == 0) IpaRelation<0>::check(x, w); else IpaRelation<1>::check(x, w);
+    return 0;
+  });
+}
+// one round of the k-ary protocol (bp_rec_kary.rs:27-190); both return the next vector length
+int arkbp_kary_prove_step(int curve, size_t k, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen,
+                          const uint64_t* result, const uint64_t* a, const uint64_t* b, size_t n, const uint8_t* fs_seed,
+                          uint64_t* pos_cross, uint64_t* neg_cross, uint64_t* a_gens_next, uint64_t* b_gens_next,
+                          uint64_t* a_next, uint64_t* b_next, uint64_t* result_next) {
+  return guarded([&] {
+    return BY_CURVE(kary_prove_step, k, a_gens, b_gens, ip_gen, result, a, b, n, fs_seed, pos_cross, neg_cross, a_gens_next,
+                    b_gens_next, a_next, b_next, result_next);
+  });
+}
+int arkbp_kary_verify_step(int curve, size_t k, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen,
+                           const uint64_t* result, size_t n, const uint64_t* pos_cross, const uint64_t* neg_cross,
+                           const uint8_t* fs_seed, uint64_t* a_gens_next, uint64_t* b_gens_next, uint64_t* result_next) {
+  return guarded([&] {
+    return BY_CURVE(kary_verify_step, k, a_gens, b_gens, ip_gen, result, n, pos_cross, neg_cross, fs_seed, a_gens_next,
+                    b_gens_next, result_next);
+  });
+}
+// padding helpers on 32-byte elements (util/mod.rs:103-134): mode 0 = zero_pad_to_multiple,
+// 1 = zero_intersperse_to_multiple; returns the output length (out holds at least n + k elements)
+long arkbp_pad(int mode, const uint64_t* in, size_t n, size_t k, uint64_t* out) {
+  return guarded([&] {
+    std::vector<Fr> v(n);
+    if (n) std::memcpy(v.data(), in, n * 32);
+    Fr zero{};
+    std::vector<Fr> o = mode == 0 ? util::zero_pad_to_multiple(v, k, zero) : util::zero_intersperse_to_multiple(v, k, zero);
+    std::memcpy(out, o.data(), o.size() * 32);
+    return (int)o.size();
   });
 }
 }

@@ -754,6 +754,55 @@ def bp_2ary_step_verify(c: Curve, inst: IpaInstance, proof, fs: FiatShamirRng) -
     return IpaInstance(A2, B2, inst.ip_gen, jac_to_affine(c, p2))
 
 
+def kary_prove_step(c: Curve, k: int, inst: IpaInstance, wit: IpaWitness, fs: FiatShamirRng):
+    """ref: src/proofs/bp_rec_kary.rs:27-143 -> (next instance, next witness, pos_cross,
+    neg_cross, x); cross terms normalised before they are absorbed."""
+    a = zero_pad_to_multiple(wit.a, k, 0)
+    b = zero_pad_to_multiple(wit.b, k, 0)
+    A = zero_pad_to_multiple([to_jac(g) for g in inst.a_gens], k, JAC_INF)
+    B = zero_pad_to_multiple([to_jac(g) for g in inst.b_gens], k, JAC_INF)
+    q = to_jac(inst.ip_gen)
+    ck = len(a) // k
+    ch = lambda v, i: v[i * ck:(i + 1) * ck]  # noqa: E731
+
+    def x_term(i, j):
+        return msm_pippenger(c, ch(A, j) + ch(B, i) + [q], ch(a, i) + ch(b, j) + [ip(c, ch(a, i), ch(b, j))])
+
+    def total(ts):
+        acc = JAC_INF
+        for t in ts:
+            acc = jac_add(c, acc, t)
+        return jac_to_affine(c, acc)
+
+    pos = [total([x_term(i + j + 1, j) for j in range(k - i - 1)]) for i in range(k - 1)]
+    neg = [total([x_term(j, i + j + 1) for j in range(k - i - 1)]) for i in range(k - 1)]
+    fs.absorb(b"".join(point_bytes_normalised(p) for p in pos))
+    fs.absorb(b"".join(point_bytes_normalised(p) for p in neg))
+    x = fs.rand_scalar(c)
+    x_inv = pow(x, -1, c.r)
+    xp, xip = powers(c, x, 0, k), powers(c, x_inv, 0, k)
+    a2, b2 = fold_scalars_kary(c, a, k, xp), fold_scalars_kary(c, b, k, xip)
+    A2 = [jac_to_affine(c, g) for g in fold_points_kary(c, A, k, xip)]
+    B2 = [jac_to_affine(c, g) for g in fold_points_kary(c, B, k, xp)]
+    p2 = msm_naive(c, [to_jac(t) for t in pos + neg] + [to_jac(inst.result)], xp[1:] + xip[1:] + [1])
+    return IpaInstance(A2, B2, inst.ip_gen, jac_to_affine(c, p2)), IpaWitness(a2, b2), pos, neg, x
+
+
+def kary_verify_step(c: Curve, k: int, inst: IpaInstance, pos, neg, fs: FiatShamirRng) -> IpaInstance:
+    """ref: src/proofs/bp_rec_kary.rs:145-190."""
+    A = zero_pad_to_multiple([to_jac(g) for g in inst.a_gens], k, JAC_INF)
+    B = zero_pad_to_multiple([to_jac(g) for g in inst.b_gens], k, JAC_INF)
+    fs.absorb(b"".join(point_bytes_normalised(p) for p in pos))
+    fs.absorb(b"".join(point_bytes_normalised(p) for p in neg))
+    x = fs.rand_scalar(c)
+    x_inv = pow(x, -1, c.r)
+    xp, xip = powers(c, x, 0, k), powers(c, x_inv, 0, k)
+    A2 = [jac_to_affine(c, g) for g in fold_points_kary(c, A, k, xip)]
+    B2 = [jac_to_affine(c, g) for g in fold_points_kary(c, B, k, xp)]
+    p2 = msm_naive(c, [to_jac(t) for t in list(pos) + list(neg)] + [to_jac(inst.result)], xp[1:] + xip[1:] + [1])
+    return IpaInstance(A2, B2, inst.ip_gen, jac_to_affine(c, p2))
+
+
 # ---------------------------------------------------------------------------
 # Byte encodings shared by the golden fixtures and the C-ABI tests
 # ---------------------------------------------------------------------------

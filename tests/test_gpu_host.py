@@ -124,3 +124,30 @@ def test_prove_with_device_resident_generators(bp, c, n):
             bp.bp_prove_cached(g2, np.concatenate([a, a]), np.concatenate([b, b]), seed)
         finally:
             g2.free()
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,k", [(4, 2), (5, 3), (8, 4), (9, 4), (7, 7)])
+def test_kary_step(bp, c, n, k):
+    """One round of the k-ary protocol (src/proofs/bp_rec_kary.rs:27-190; the reference tests it
+    through test_kary_bp_ipa, src/lib.rs:207-213): cross terms, challenge-folded vectors and
+    result are bit-identical to the big-integer model's, the folded pair satisfies the relation
+    (the reference's debug_assert, :117-125) and verify_step reproduces the instance."""
+    cid = c.curve_id
+    inst, wit = pm.sample_ipa(c, pm.test_rng(), n)
+    seed = bytes(range(32))
+    A, B, q = H.jac_abi(c, inst.a_gens), H.jac_abi(c, inst.b_gens), H.jac_abi(c, [inst.ip_gen])
+    res, a, b = H.jac_abi(c, [inst.result]), H.scalars_abi(c, wit.a), H.scalars_abi(c, wit.b)
+    got = bp.kary_prove_step(cid, k, A, B, q, res, a, b, seed)
+    inst2, wit2, pos, neg, x = pm.kary_prove_step(c, k, inst, wit, pm.FiatShamirRng(seed))
+    assert H.jac_from_abi(c, got["pos_cross"]) == pos and H.jac_from_abi(c, got["neg_cross"]) == neg
+    assert H.scalars_from_abi(c, got["a"]) == wit2.a and H.scalars_from_abi(c, got["b"]) == wit2.b
+    assert H.jac_from_abi(c, got["a_gens"]) == inst2.a_gens and H.jac_from_abi(c, got["b_gens"]) == inst2.b_gens
+    assert H.jac_from_abi(c, got["result"]) == [inst2.result]
+    bp.ipa_check(cid, got["a_gens"], got["b_gens"], q, got["result"], got["a"], got["b"])
+    v = bp.kary_verify_step(cid, k, A, B, q, res, got["pos_cross"], got["neg_cross"], seed)
+    assert (v["a_gens"] == got["a_gens"]).all() and (v["b_gens"] == got["b_gens"]).all() and (v["result"] == got["result"]).all()
+    with pytest.raises(bp.Panic):   # a tampered witness no longer satisfies the folded relation
+        bad = got["a"].copy()
+        bad[0, 0] ^= np.uint64(1)
+        bp.ipa_check(cid, got["a_gens"], got["b_gens"], q, got["result"], bad, got["b"])

@@ -28,3 +28,21 @@ def test_scalar_inverse_and_zero_panics(c):
         assert got == pow(x, -1, c.r)
     with pytest.raises(ark_bp.Panic):
         ark_bp.scalar_inverse(c.curve_id, np.zeros(4, np.uint64))   # x.inverse().unwrap() on zero
+
+
+# the reference's own exact-value tests (src/util/mod.rs:154-201, Pallas Fr) on the host mirror
+@pytest.mark.parametrize("xs,k,want", [([1, 2, 3, 4], 3, [1, 2, 3, 0, 4, 0]), ([1, 2, 3, 4, 5, 6], 3, [1, 2, 3, 4, 5, 6]),
+                                       ([1, 2, 3, 4, 5], 3, [1, 2, 3, 4, 5, 0])])
+def test_zero_intersperse_reference_known_answers(xs, k, want):
+    c = pm.PALLAS
+    got = ark_bp.pad(1, H.scalars_abi(c, xs), k)
+    assert (got == H.scalars_abi(c, want)).all()
+
+
+def test_zero_pad_to_multiple_host():
+    c = pm.PALLAS
+    for n, k in [(1, 3), (3, 3), (4, 3), (7, 4), (5, 8)]:
+        xs = list(range(1, n + 1))
+        assert H.scalars_from_abi(c, ark_bp.pad(0, H.scalars_abi(c, xs), k)) == pm.zero_pad_to_multiple(xs, k, 0)
+    with pytest.raises(ark_bp.Panic):   # (len - 1) underflows in the reference
+        ark_bp.pad(0, np.zeros((0, 4), np.uint64), 3)

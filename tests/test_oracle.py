@@ -244,3 +244,20 @@ def test_kary_utilities_c_vs_model(c):
     a[3] = 0
     want = [pm.jac_to_affine(c, p) for p in pm.hadamard_gp(c, [pm.to_jac(p) for p in g], a)]
     assert H.jac_from_abi(c, co.hadamard_points(cid, H.jac_abi(c, g), H.scalars_abi(c, a))) == want
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,k", [(4, 2), (5, 3), (6, 3)])
+def test_kary_step_model_invariants(c, n, k):
+    """bp_rec_kary.rs prove_step: the folded instance satisfies the relation (the reference's
+    debug_assert, :117-125) and verify_step reproduces it (test_reduction, src/lib.rs:215-229)."""
+    inst, wit = pm.sample_ipa(c, pm.test_rng(), n)
+    seed = bytes(range(32))
+    inst2, wit2, pos, neg, x = pm.kary_prove_step(c, k, inst, wit, pm.FiatShamirRng(seed))
+    assert len(pos) == len(neg) == k - 1 and len(wit2.a) == (n - 1) // k + 1
+    assert pm.ipa_check(c, inst2, wit2)
+    v = pm.kary_verify_step(c, k, inst, pos, neg, pm.FiatShamirRng(seed))
+    assert v == inst2
+    if k == 2 and n % 2 == 0:   # k = 2 is the classic round with L = neg cross term, R = pos cross term
+        (l, r), i2, w2, x2 = pm.bp_2ary_step_prove(c, inst, wit, pm.FiatShamirRng(seed))
+        assert [l] == neg and [r] == pos
