@@ -119,12 +119,26 @@ def bp_prove_cached(gens: DeviceGens, a, b, fs_seed: bytes):
 
 
 def bp_verify(curve, a_gens, b_gens, ip_gen, result, proof, fs_seed: bytes):
-    """Bp::verify: returns None, raises Panic where the reference's assert_eq! fails."""
+    """Bp::verify: returns the verify time in ms, raises Panic where the reference's assert_eq! fails."""
     A, B, q, res = _u64(a_gens, 12), _u64(b_gens, 12), _u64(ip_gen, 12), _u64(result, 12)
     ls, rs = _u64(proof["ls"], 12), _u64(proof["rs"], 12)
     seed = np.frombuffer(fs_seed, np.uint8).copy()
+    ms = c_double()
     _check(load().arkbp_bp_verify(curve, _p(A), _p(B), _p(q), _p(res), c_size_t(len(A)), _p(ls), _p(rs), c_size_t(len(ls)),
-                                  _p(_u64(proof["final_a"], 4)), _p(_u64(proof["final_b"], 4)), _p(seed)))
+                                  _p(_u64(proof["final_a"], 4)), _p(_u64(proof["final_b"], 4)), _p(seed), ctypes.byref(ms)))
+    return ms.value
+
+
+def bp_verify_cached(gens: DeviceGens, result, proof, fs_seed: bytes):
+    """Bp::verify with the generators already in HBM; returns the verify time in ms."""
+    res = _u64(result, 12)
+    ls, rs = _u64(proof["ls"], 12), _u64(proof["rs"], 12)
+    seed = np.frombuffer(fs_seed, np.uint8).copy()
+    ms = c_double()
+    _check(load().arkbp_bp_verify_cached(gens.curve, ctypes.c_void_p(gens.h), _p(res), c_size_t(gens.n), _p(ls), _p(rs),
+                                         c_size_t(len(ls)), _p(_u64(proof["final_a"], 4)), _p(_u64(proof["final_b"], 4)),
+                                         _p(seed), ctypes.byref(ms)))
+    return ms.value
 
 
 def step_prove(curve, a_gens, b_gens, ip_gen, result, a, b, fs_seed: bytes):

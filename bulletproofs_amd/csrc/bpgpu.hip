@@ -1177,6 +1177,141 @@ int bpgpu_fold_points(int curve, const uint64_t* g_xyz, size_t n_out, const uint
   return 0;
 }
 
+// ---- verifier MSM of Bp::verify ----------------------------------------------------
+extern "C++" {
+namespace {
+template <int SF>
+int verify_tables(const uint64_t* challenges, size_t k, const uint64_t final_a[4], const uint64_t final_b[4],
+                  std::vector<uint64_t>& tab, std::vector<uint64_t>& tail) {
+  using HFs = host::HF<SF>;
+  auto ld = [](const uint64_t* p) {
+    host::H4 r;
+    memcpy(r.v, p, 32);
+    return r;
+  };
+  host::H4 fa = ld(final_a), fb = ld(final_b), base_a = fa, base_b = fb;
+  tab.assign((2 + 2 * k) * 4, 0);
+  tail.assign((1 + 2 * k) * 4, 0);
+  host::H4 ab = HFs::mul(fa, fb);
+  memcpy(&tail[0], ab.v, 32);
+  for (size_t j = 0; j < k; j++) {
+    host::H4 x = ld(challenges + 4 * j);
+    if (HFs::is_zero(x)) return fail(BPGPU_E_ARG, "challenge %zu is zero (no inverse)", j);
+    host::H4 xi = HFs::inv(x), x2 = HFs::sqr(x), xi2 = HFs::sqr(xi);
+    base_a = HFs::mul(base_a, xi);
+    base_b = HFs::mul(base_b, x);
+    const size_t t = k - 1 - j;  // bit of the index this challenge acts on
+    memcpy(&tab[(2 + t) * 4], x2.v, 32);
+    memcpy(&tab[(2 + k + t) * 4], xi2.v, 32);
+    host::H4 n2 = HFs::neg(x2), ni2 = HFs::neg(xi2);  // -x^2 on L_j, -x^-2 on R_j (bp_iter.rs:166-173)
+    memcpy(&tail[(1 + 2 * j) * 4], n2.v, 32);
+    memcpy(&tail[(2 + 2 * j) * 4], ni2.v, 32);
+  }
+  memcpy(&tab[0], base_a.v, 32);
+  memcpy(&tab[4], base_b.v, 32);
+  return 0;
+}
+
+// points: A | B | Q | L_0 R_0 L_1 R_1 ... ; gens from the host (jacobian) or the device (dev affine)
+int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
+                      const void* d_a, const void* d_b, const void* d_q, size_t n, const uint64_t* ls_xyz,
+                      const uint64_t* rs_xyz, size_t k, const uint64_t* challenges, const uint64_t final_a[4],
+                      const uint64_t final_b[4], uint64_t out_xy_inf[9]) {
+  Ctx& C = g_ctx;
+  const bool from_device = d_q != nullptr;
+  if (k > 30) return fail(BPGPU_E_ARG, "too many rounds");
+  const size_t np = (size_t)1 << k;
+  if (pow2_at_least(n < 1 ? 1 : n) != np) return fail(BPGPU_E_ARG, "proof has %zu rounds but the generators need %zu elements", k, n);
+  const size_t total = 2 * np + 1 + 2 * k;
+  std::vector<uint64_t> tab, tail;
+  TRY(curve == BPGPU_PALLAS ? verify_tables<1>(challenges, k, final_a, final_b, tab, tail)
+                            : verify_tables<0>(challenges, k, final_a, final_b, tab, tail));
+  TRY(C.st_pts.ensure(total * 64));
+  TRY(C.st_sc.ensure(total * 32));
+  TRY(C.st_ip.ensure(tab.size() * 8));
+  hipStream_t st = C.stream;
+  uint32_t* dp = C.st_pts.as<uint32_t>();
+  uint32_t* ds = C.st_sc.as<uint32_t>();
+  HIP_TRY(hipMemcpyAsync(C.st_ip.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ds + 8ull * 2 * np, tail.data(), tail.size() * 8, hipMemcpyHostToDevice, st));
+  // generators, zero-padded to np with identity points (bp_iter.rs:137-138)
+  if (np > n) {
+    HIP_TRY(hipMemsetAsync(dp + 16ull * n, 0, (np - n) * 64, st));
+    HIP_TRY(hipMemsetAsync(dp + 16ull * (np + n), 0, (np - n) * 64, st));
+  }
+  // staging for the jacobian inputs: the proof's points always, the generators when they come from the host
+  const size_t stage_pts = (from_device ? 0 : 2 * n + 1) + 2 * k;
+  TRY(C.st_pts_in.ensure((stage_pts ? stage_pts : 1) * 96));
+  uint8_t* stg = (uint8_t*)C.st_pts_in.p;
+  size_t so = 0;
+  if (from_device) {
+    if (n) {
+      HIP_TRY(hipMemcpyAsync(dp, d_a, n * 64, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(dp + 16ull * np, d_b, n * 64, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(dp + 16ull * 2 * np, d_q, 64, hipMemcpyDeviceToDevice, st));
+  } else {
+    if (n) {
+      HIP_TRY(hipMemcpyAsync(stg, a_gens_xyz, n * 96, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(stg + n * 96, b_gens_xyz, n * 96, hipMemcpyHostToDevice, st));
+      TRY(points_in(curve, (uint32_t*)stg, dp, n, 0));
+      TRY(points_in(curve, (uint32_t*)(stg + n * 96), dp + 16ull * np, n, 0));
+    }
+    HIP_TRY(hipMemcpyAsync(stg + 2 * n * 96, ip_gen_xyz, 96, hipMemcpyHostToDevice, st));
+    TRY(points_in(curve, (uint32_t*)(stg + 2 * n * 96), dp + 16ull * 2 * np, 1, 0));
+    so = (2 * n + 1) * 96;
+  }
+  if (k) {
+    // interleave L_j, R_j on the host side of the staging copy
+    std::vector<uint64_t> lr(2 * k * 12);
+    for (size_t j = 0; j < k; j++) {
+      memcpy(&lr[(2 * j) * 12], ls_xyz + 12 * j, 96);
+      memcpy(&lr[(2 * j + 1) * 12], rs_xyz + 12 * j, 96);
+    }
+    HIP_TRY(hipMemcpyAsync(stg + so, lr.data(), 2 * k * 96, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // lr, tab and tail live on this frame
+    TRY(points_in(curve, (uint32_t*)(stg + so), dp + 16ull * (2 * np + 1), 2 * k, 0));
+  } else {
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  uint32_t gx = cdiv(np, 256);
+  if (gx > (uint32_t)C.num_cus * 8) gx = (uint32_t)C.num_cus * 8;
+  if (curve == BPGPU_PALLAS)
+    k_verify_scalars<1><<<dim3(gx, 2), 256, 0, st>>>(C.st_ip.as<uint32_t>(), ds, (uint32_t)np, (int)k);
+  else
+    k_verify_scalars<0><<<dim3(gx, 2), 256, 0, st>>>(C.st_ip.as<uint32_t>(), ds, (uint32_t)np, (int)k);
+  HIP_TRY(hipGetLastError());
+  return msm_dispatch(curve, dp, ds, single_plan((uint32_t)total), (uint64_t(*)[9])out_xy_inf);
+}
+}  // namespace
+}  // extern "C++"
+
+int bpgpu_ipa_verify_msm(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
+                         size_t n, const uint64_t* ls_xyz, const uint64_t* rs_xyz, size_t k, const uint64_t* challenges,
+                         const uint64_t final_a[4], const uint64_t final_b[4], uint64_t out_xy_inf[9]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!ip_gen_xyz || !final_a || !final_b || !out_xy_inf) return fail(BPGPU_E_ARG, "null pointer");
+  if (n && (!a_gens_xyz || !b_gens_xyz)) return fail(BPGPU_E_ARG, "null pointer");
+  if (k && (!ls_xyz || !rs_xyz || !challenges)) return fail(BPGPU_E_ARG, "null pointer");
+  return verify_msm_common(curve, a_gens_xyz, b_gens_xyz, ip_gen_xyz, nullptr, nullptr, nullptr, n, ls_xyz, rs_xyz, k,
+                           challenges, final_a, final_b, out_xy_inf);
+}
+
+int bpgpu_ipa_verify_msm_device(int curve, const void* d_a_gens, const void* d_b_gens, const void* d_ip_gen, size_t n,
+                                const uint64_t* ls_xyz, const uint64_t* rs_xyz, size_t k, const uint64_t* challenges,
+                                const uint64_t final_a[4], const uint64_t final_b[4], uint64_t out_xy_inf[9]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!d_ip_gen || !final_a || !final_b || !out_xy_inf) return fail(BPGPU_E_ARG, "null pointer");
+  if (n && (!d_a_gens || !d_b_gens)) return fail(BPGPU_E_ARG, "null pointer");
+  if (k && (!ls_xyz || !rs_xyz || !challenges)) return fail(BPGPU_E_ARG, "null pointer");
+  return verify_msm_common(curve, nullptr, nullptr, nullptr, d_a_gens, d_b_gens, d_ip_gen, n, ls_xyz, rs_xyz, k, challenges,
+                           final_a, final_b, out_xy_inf);
+}
+
 // ---- vector utilities of the k-ary protocols ----------------------------------
 extern "C++" {
 namespace {

@@ -1289,6 +1289,49 @@ __global__ void __launch_bounds__(256) k_hadamard_points(const uint32_t* g, cons
   }
 }
 
+// Verifier scalars of Bp::verify (bp_iter.rs:25-42,160-164), 2 np of them:
+//   o[i]      = final_a * s_i,      s_i     = prod_t (bit t of i ? x_{K-1-t} : x_{K-1-t}^-1)
+//   o[np + i] = final_b * s_inv_i,  s_inv_i = the same product over the inverted challenges
+// written as base * prod_{set bits} (square of the challenge):  tab = [base_a, base_b, sq_0 .. sq_{K-1},
+// sqi_0 .. sqi_{K-1}] (ark form, device memory) with base_a = final_a prod x^-1, sq_t = x_{K-1-t}^2,
+// base_b = final_b prod x, sqi_t = x_{K-1-t}^-2.  blockIdx.y: 0 = the a half, 1 = the b half.
+template <int SF>
+__global__ void __launch_bounds__(256) k_verify_scalars(const uint32_t* __restrict__ tab, uint32_t* __restrict__ o,
+                                                        uint32_t np, int K) {
+  using F = Fp<SF>;
+  __shared__ int32_t sq[32 * 9];
+  const uint32_t half = blockIdx.y;
+  if (threadIdx.x < (uint32_t)K) {
+    uint32_t w[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) w[t] = tab[8ull * (2 + half * K + threadIdx.x) + t];
+    const Fe m = F::load_ark(w);
+#pragma unroll
+    for (int t = 0; t < 9; t++) sq[9 * threadIdx.x + t] = m.l[t];
+  }
+  __syncthreads();
+  uint32_t wb[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) wb[t] = tab[8ull * half + t];
+  const Fe base = F::unpack(wb);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) {
+    Fe s = base;
+    for (int t = 0; t < K; t++) {
+      if ((i >> t) & 1u) {
+        Fe m;
+#pragma unroll
+        for (int u = 0; u < 9; u++) m.l[u] = sq[9 * t + u];
+        s = F::mul(s, m);  // ark form times device form stays ark form
+      }
+    }
+    uint32_t w[8];
+    F::store_packed(s, w);
+    uint4* po = reinterpret_cast<uint4*>(o + 8ull * ((uint64_t)half * np + i));
+    po[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    po[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
 // Register-only multiply-add loop: sustained v_mad_u64_u32 issue rate (the integer
 // roofline the MSM and the generator fold are priced against).
 __global__ void __launch_bounds__(256) k_mad_peak(uint32_t* out, uint32_t seed, int iters) {

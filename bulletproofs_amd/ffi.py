@@ -48,6 +48,10 @@ SIGNATURES = {
     "bpgpu_powers": (c_int, [c_int, c_void_p, c_uint64, c_size_t, c_void_p]),
     "bpgpu_ipa_begin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
     "bpgpu_ipa_begin_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "bpgpu_ipa_verify_msm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
+    "bpgpu_ipa_verify_msm_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
     "bpgpu_ipa_len": (c_size_t, [c_void_p]),
     "bpgpu_ipa_round_lr": (c_int, [c_void_p, c_void_p, c_void_p]),
     "bpgpu_ipa_round_fold": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -209,6 +213,25 @@ def powers(curve, f, start, end):
     n = max(0, end - start)
     out = np.zeros((n, 4), dtype=np.uint64)
     _check(load().bpgpu_powers(curve, _ptr(_u64(f)), start, n, _ptr(out)))
+    return out
+
+
+def ipa_verify_msm(curve, a_gens_xyz, b_gens_xyz, ip_gen_xyz, ls_xyz, rs_xyz, challenges, final_a, final_b, d_gens=None):
+    """Right-hand side of Bp::verify (bp_iter.rs:160-176) -> xy_inf.  d_gens = (d_a, d_b, d_q, n) uses
+    generators already in HBM."""
+    ls, rs, ch = _u64(ls_xyz, 12), _u64(rs_xyz, 12), _u64(challenges, 4)
+    k = len(ls)
+    assert len(rs) == k and len(ch) == k
+    out = np.zeros(9, dtype=np.uint64)
+    if d_gens is not None:
+        d_a, d_b, d_q, n = d_gens
+        _check(load().bpgpu_ipa_verify_msm_device(curve, d_a.ptr, d_b.ptr, d_q.ptr, n, _ptr(ls), _ptr(rs), k, _ptr(ch),
+                                                  _ptr(_u64(final_a)), _ptr(_u64(final_b)), _ptr(out)))
+    else:
+        A, B, q = _u64(a_gens_xyz, 12), _u64(b_gens_xyz, 12), _u64(ip_gen_xyz, 12)
+        assert len(A) == len(B)
+        _check(load().bpgpu_ipa_verify_msm(curve, _ptr(A), _ptr(B), _ptr(q), len(A), _ptr(ls), _ptr(rs), k, _ptr(ch),
+                                           _ptr(_u64(final_a)), _ptr(_u64(final_b)), _ptr(out)))
     return out
 
 

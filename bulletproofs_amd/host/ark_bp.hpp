@@ -544,37 +544,36 @@ struct Bp {
     return left;
   }
 
-  // bp_iter.rs:130-178: panics (throws) unless the single big MSM reproduces the commitment
-  static void verify(const IpaInstance& instance, const BpProof& proof, FiatShamirRng& fs) {
-    std::vector<G> a_gen = util::zero_pad_to_two_power(instance.gens.a_gens, zero_point<CURVE>());
-    std::vector<G> b_gen = util::zero_pad_to_two_power(instance.gens.b_gens, zero_point<CURVE>());
-    std::vector<Fr> challenges, challenges_inv;
-    for (size_t i = 0; i < proof.ls.size(); i++) {
+  // bp_iter.rs:130-178: panics (throws) unless the single big MSM reproduces the commitment.  The
+  // transcript is replayed here; the 2N + 1 + 2 log2 N scalars (scalars_from_challenges above and its
+  // inverse twin, :160-173) are expanded on the device and the MSM runs there (bpgpu_ipa_verify_msm).
+  // `cached`, when given, must hold instance.gens.
+  static void verify(const IpaInstance& instance, const BpProof& proof, FiatShamirRng& fs,
+                     const DeviceGens* cached = nullptr) {
+    const size_t n = instance.gens.a_gens.size(), k = proof.ls.size();
+    if (instance.gens.b_gens.size() != n || proof.rs.size() != k) throw Panic("assertion failed: vector sizes");
+    std::vector<Fr> challenges;
+    for (size_t i = 0; i < k; i++) {
       fs.absorb<CURVE>(proof.ls[i]);
       fs.absorb<CURVE>(proof.rs[i]);
       challenges.push_back(fs.rand_scalar<CURVE>());
     }
-    for (const Fr& c : challenges) challenges_inv.push_back(S::inverse(c));
-    std::vector<Fr> scalars = scalars_from_challenges(challenges);
-    std::vector<Fr> scalars_inv = scalars_from_challenges(challenges_inv);
-    if (scalars.size() != a_gen.size()) throw Panic("assertion failed: proof length does not match the generators");
-    std::vector<G> pts;
-    std::vector<Fr> sc;
-    pts.reserve(2 * a_gen.size() + 1 + 2 * proof.ls.size());
-    sc.reserve(pts.capacity());
-    pts.insert(pts.end(), a_gen.begin(), a_gen.end());
-    for (const Fr& s : scalars) sc.push_back(S::mul(s, proof.final_a));
-    pts.insert(pts.end(), b_gen.begin(), b_gen.end());
-    for (const Fr& s : scalars_inv) sc.push_back(S::mul(s, proof.final_b));
-    pts.push_back(instance.gens.ip_gen);
-    sc.push_back(S::mul(proof.final_a, proof.final_b));
-    for (size_t j = 0; j < proof.ls.size(); j++) {
-      pts.push_back(proof.ls[j]);
-      sc.push_back(S::neg(S::square(challenges[j])));
-      pts.push_back(proof.rs[j]);
-      sc.push_back(S::neg(S::square(challenges_inv[j])));
+    if (k > 30 || util::next_power_of_two(n < 1 ? 1 : n) != ((size_t)1 << k))
+      throw Panic("assertion failed: proof length does not match the generators");
+    uint64_t out[9];
+    const uint64_t* ls = k ? proof.ls.data()->v : nullptr;
+    const uint64_t* rs = k ? proof.rs.data()->v : nullptr;
+    const uint64_t* ch = k ? challenges.data()->v : nullptr;
+    if (cached) {
+      if (cached->n != n || cached->curve != CURVE) throw Panic("assertion failed: cached generators do not match");
+      check(bpgpu_ipa_verify_msm_device(CURVE, cached->a, cached->b, cached->q, n, ls, rs, k, ch, proof.final_a.v,
+                                        proof.final_b.v, out));
+    } else {
+      check(bpgpu_ipa_verify_msm(CURVE, n ? instance.gens.a_gens.data()->v : nullptr,
+                                 n ? instance.gens.b_gens.data()->v : nullptr, instance.gens.ip_gen.v, n, ls, rs, k, ch,
+                                 proof.final_a.v, proof.final_b.v, out));
     }
-    if (!(instance.result == util::msm<CURVE>(pts, sc))) throw Panic("assertion failed: `(left == right)` in Bp::verify");
+    if (!(instance.result == P::from_xy_inf(out))) throw Panic("assertion failed: `(left == right)` in Bp::verify");
   }
   static size_t proof_size(const BpProof& p) { return 2 * (1 + p.ls.size()); }  // bp_iter.rs:187-189
 };

@@ -100,8 +100,16 @@ int bp_prove_cached(const DeviceGens* dg, const uint64_t* a, const uint64_t* b, 
 template <int CURVE>
 int bp_verify(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen, const uint64_t* result, size_t n,
               const uint64_t* ls, const uint64_t* rs, size_t k, const uint64_t* final_a, const uint64_t* final_b,
-              const uint8_t* fs_seed) {
-  IpaInstance x = make_instance(a_gens, b_gens, ip_gen, result, n);
+              const uint8_t* fs_seed, const DeviceGens* cached, double* verify_ms) {
+  IpaInstance x;
+  if (cached) {  // the host copy of the generators is not needed: sizes, ip_gen and result only
+    x.gens.vec_size = n;
+    x.gens.a_gens.resize(n);
+    x.gens.b_gens.resize(n);
+    std::memcpy(x.result.v, result, 96);
+  } else {
+    x = make_instance(a_gens, b_gens, ip_gen, result, n);
+  }
   BpProof pf;
   pf.ls.resize(k);
   pf.rs.resize(k);
@@ -112,7 +120,10 @@ int bp_verify(const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip
   std::memcpy(pf.final_a.v, final_a, 32);
   std::memcpy(pf.final_b.v, final_b, 32);
   FiatShamirRng fs = FiatShamirRng::from_seed(fs_seed, 32);
-  Bp<CURVE>::verify(x, pf, fs);
+  auto t0 = std::chrono::steady_clock::now();
+  Bp<CURVE>::verify(x, pf, fs, cached);  // the window test_ipa times (src/lib.rs:127-131)
+  auto t1 = std::chrono::steady_clock::now();
+  if (verify_ms) *verify_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
   return 0;
 }
 
@@ -255,8 +266,19 @@ int arkbp_bp_prove_cached(int curve, const void* handle, const uint64_t* a, cons
 // 0 = accepted; -100 = the reference's verify would have panicked
 int arkbp_bp_verify(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen,
                     const uint64_t* result, size_t n, const uint64_t* ls, const uint64_t* rs, size_t k,
-                    const uint64_t* final_a, const uint64_t* final_b, const uint8_t* fs_seed) {
-  return guarded([&] { return BY_CURVE(bp_verify, a_gens, b_gens, ip_gen, result, n, ls, rs, k, final_a, final_b, fs_seed); });
+                    const uint64_t* final_a, const uint64_t* final_b, const uint8_t* fs_seed, double* verify_ms) {
+  return guarded([&] {
+    return BY_CURVE(bp_verify, a_gens, b_gens, ip_gen, result, n, ls, rs, k, final_a, final_b, fs_seed, nullptr, verify_ms);
+  });
+}
+// Bp::verify with the generators already in HBM (handle from arkbp_gens_upload)
+int arkbp_bp_verify_cached(int curve, const void* handle, const uint64_t* result, size_t n, const uint64_t* ls,
+                           const uint64_t* rs, size_t k, const uint64_t* final_a, const uint64_t* final_b,
+                           const uint8_t* fs_seed, double* verify_ms) {
+  return guarded([&] {
+    const DeviceGens* dg = static_cast<const DeviceGens*>(handle);
+    return BY_CURVE(bp_verify, nullptr, nullptr, nullptr, result, n, ls, rs, k, final_a, final_b, fs_seed, dg, verify_ms);
+  });
 }
 int arkbp_2ary_prove(int curve, const uint64_t* a_gens, const uint64_t* b_gens, const uint64_t* ip_gen,
                      const uint64_t* result, const uint64_t* a, const uint64_t* b, size_t n, const uint8_t* fs_seed,

@@ -171,6 +171,25 @@ int bpgpu_ipa_export(bpgpu_ipa* s, uint64_t* a_gens_xyz, uint64_t* b_gens_xyz, u
                      uint64_t* b);
 void bpgpu_ipa_free(bpgpu_ipa* s);
 
+/* ---- verifier MSM ("next" row f1) ----------------------------------------------------
+ * The right-hand side of Bp::verify, reference src/proofs/bp_iter.rs:130-178, as one call:
+ *   msm( A | B | Q | L_0 R_0 L_1 R_1 ...,
+ *        final_a * s | final_b * s_inv | final_a * final_b | -x_0^2, -x_0^-2, -x_1^2, ... )
+ * with s = scalars_from_challenges(challenges), s_inv = scalars_from_challenges(inverses) (:25-42)
+ * expanded on the device.  The caller replays Fiat-Shamir to obtain `challenges` (k of them, :146-153)
+ * and compares the returned point with instance.result (:176).  n: unpadded generator count; the
+ * generators are zero-padded to 2^k with identity points as :137-138 does; k must be log2 of that
+ * padded length.  A zero challenge is an error (the reference's inverse().unwrap() panics). */
+int bpgpu_ipa_verify_msm(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz,
+                         const uint64_t* ip_gen_xyz, size_t n, const uint64_t* ls_xyz,
+                         const uint64_t* rs_xyz, size_t k, const uint64_t* challenges,
+                         const uint64_t final_a[4], const uint64_t final_b[4], uint64_t out_xy_inf[9]);
+/* same with the generators already in HBM (dev affine, bpgpu_points_to_device) */
+int bpgpu_ipa_verify_msm_device(int curve, const void* d_a_gens, const void* d_b_gens, const void* d_ip_gen,
+                                size_t n, const uint64_t* ls_xyz, const uint64_t* rs_xyz, size_t k,
+                                const uint64_t* challenges, const uint64_t final_a[4],
+                                const uint64_t final_b[4], uint64_t out_xy_inf[9]);
+
 /* ---- helpers for the sharded (multi-GPU) MSM ---------------------------------
  * Each rank runs bpgpu_msm* on its contiguous point range; the per-rank results
  * (72 B each) are gathered (RCCL all_gather, done by the host language) and summed

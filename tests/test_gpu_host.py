@@ -109,6 +109,10 @@ def test_prove_with_device_resident_generators(bp, c, n):
             got = bp.bp_prove_cached(gens, a_k, b, seed)
             for key in ("ls", "rs", "challenges", "final_a", "final_b"):
                 assert (got[key] == want[key]).all(), (k, key)
+            result = bp.commit(cid, A, B, q, a_k, b)
+            bp.bp_verify_cached(gens, result, got, seed)             # Bp::verify over the same cached generators
+            with pytest.raises(bp.Panic):
+                bp.bp_verify_cached(gens, q, got, seed)             # some other commitment
         # against the oracle too (zero-padded as bp_iter.rs:59-62 does)
         np_ = 1 << max(0, (n - 1).bit_length())
         pad_p = np.tile(co.normalise(cid, np.zeros((1, 12), np.uint64)), (np_ - n, 1))

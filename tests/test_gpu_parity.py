@@ -307,3 +307,49 @@ def test_session_monic_fold_edge_cases(ffi, c):
         sess.free()
     finally:
         ffi.set_freeze_len(1 << 16)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 21, 64])
+def test_verifier_msm(ffi, c, n):
+    """bpgpu_ipa_verify_msm against the model's right-hand side of Bp::verify (bp_iter.rs:130-178):
+    scalars_from_challenges expanded on the device, generators zero-padded to a power of two.  The
+    value must match for an honest proof (= instance.result) and for a tampered one (some other point)."""
+    cid = c.curve_id
+    inst, wit = pm.sample_ipa(c, pm.test_rng(), n)
+    proof = pm.bp_prove(c, inst, wit, pm.FiatShamirRng(b"\x07" * 32))
+    A, B, q = H.jac_abi(c, inst.a_gens), H.jac_abi(c, inst.b_gens), H.jac_abi(c, [inst.ip_gen])
+
+    def model_rhs(pf, challs):
+        Ap = pm.zero_pad_to_two_power([pm.to_jac(g) for g in inst.a_gens], pm.JAC_INF)
+        Bp = pm.zero_pad_to_two_power([pm.to_jac(g) for g in inst.b_gens], pm.JAC_INF)
+        ci = [pow(x, -1, c.r) for x in challs]
+        s, si = pm.scalars_from_challenges(c, challs), pm.scalars_from_challenges(c, ci)
+        pts = Ap + Bp + [pm.to_jac(inst.ip_gen)]
+        scs = [v * pf.final_a % c.r for v in s] + [v * pf.final_b % c.r for v in si] + [pf.final_a * pf.final_b % c.r]
+        for j in range(len(pf.ls)):
+            pts += [pm.to_jac(pf.ls[j]), pm.to_jac(pf.rs[j])]
+            scs += [(-challs[j] * challs[j]) % c.r, (-ci[j] * ci[j]) % c.r]
+        return pm.jac_to_affine(c, pm.msm_naive(c, pts, scs))
+
+    def gpu_rhs(pf, challs, **kw):
+        return H.xy_inf_to_affine(c, ffi.ipa_verify_msm(cid, A, B, q, H.jac_abi(c, pf.ls), H.jac_abi(c, pf.rs),
+                                                        H.scalars_abi(c, challs), H.scalar_abi(c, pf.final_a),
+                                                        H.scalar_abi(c, pf.final_b), **kw))
+
+    assert gpu_rhs(proof, proof.challenges) == inst.result == model_rhs(proof, proof.challenges)
+    bad = pm.BpProof(proof.ls, proof.rs, proof.final_b, (proof.final_a + 1) % c.r, proof.challenges)
+    other = [(x * 3 + 1) % c.r for x in proof.challenges]
+    assert gpu_rhs(bad, other) == model_rhs(bad, other)
+    assert model_rhs(bad, other) != inst.result
+    # generators already in HBM
+    d_a, d_b, d_q = ffi.points_to_device(cid, A), ffi.points_to_device(cid, B), ffi.points_to_device(cid, q)
+    assert gpu_rhs(proof, proof.challenges, d_gens=(d_a, d_b, d_q, n)) == inst.result
+    for d in (d_a, d_b, d_q):
+        d.free()
+    if len(proof.ls):   # wrong number of rounds, zero challenge: errors (the reference panics)
+        with pytest.raises(Exception):
+            ffi.ipa_verify_msm(cid, A, B, q, H.jac_abi(c, proof.ls[:-1]), H.jac_abi(c, proof.rs[:-1]),
+                               H.scalars_abi(c, proof.challenges[:-1]), H.scalar_abi(c, 1), H.scalar_abi(c, 1))
+        with pytest.raises(Exception):
+            gpu_rhs(proof, [0] * len(proof.challenges))
