@@ -348,12 +348,13 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     const uint32_t outputs = (uint32_t)(comps * plan.M * W), half = runs_per_window >> 1;
     uint32_t slices = 1;
     while (slices < 64 && 2 * slices * outputs <= 2048 && 2 * slices * 64 <= half) slices *= 2;
-    TRY(C.redtmp.ensure((size_t)outputs * slices * 128));
-    k_reduce2<BF><<<dim3(comps, plan.M * W, cdiv(slices, 4)), 256, 0, st>>>(
+    const uint32_t groups = cdiv(slices, 4);  // a workgroup adds up its four slices itself
+    TRY(C.redtmp.ensure((size_t)outputs * groups * 128));
+    k_reduce2<BF><<<dim3(comps, plan.M * W, groups), 256, 0, st>>>(
         C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window, slices);
-    if (slices > 1)
-      k_reduce3<BF><<<cdiv(outputs * slices, 256), 256, 0, st>>>(C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), outputs,
-                                                                  slices);
+    if (groups > 1)
+      k_reduce3<BF><<<cdiv(outputs * groups, 256), 256, 0, st>>>(C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), outputs,
+                                                                  groups);
   }
   HIP_TRY(hipEventRecord(C.ev[5], st));
   TRY(C.h_winsum.ensure((size_t)plan.M * W * comps * 128));

@@ -553,42 +553,70 @@ __global__ void __launch_bounds__(256) k_reduce1(const uint32_t* __restrict__ bs
 
 // grid = (2 + nbits, windows, ceil(slices / 4)); components 0 and 1 = the two halves of P, component
 // 2+i = U_i.  A component sums per/2 values; it is cut into `slices` slices, one wave each: lanes
-// first (every lane busy), then the wave.  slices == 1 writes the result (ark-form XYZZ) to out,
-// otherwise the slice sums go to tmp and k_reduce3 adds them up.
+// first (every lane busy), then the wave, then the (up to) four waves of the workgroup through LDS --
+// the addition code is already in the instruction cache here, whereas a separate small kernel for that
+// last step pays more in cold instruction fetches than in arithmetic.  With slices <= 4 the result
+// (ark-form XYZZ) goes to out; otherwise one sum per workgroup goes to tmp and k_reduce3 adds them up.
 template <int BF>
 __global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tmp,
                                                  uint32_t* __restrict__ out, uint32_t per, uint32_t slices) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
-  const uint32_t comp = blockIdx.x, w = blockIdx.y, lane = threadIdx.x & 63u;
-  const uint32_t slice = blockIdx.z * 4 + (threadIdx.x >> 6);
-  if (slice >= slices) return;
+  __shared__ int32_t xs[4][37];
+  const uint32_t comp = blockIdx.x, w = blockIdx.y, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t slice = blockIdx.z * 4 + wave;
   const uint32_t half = per >> 1;  // per is a power of two; per = 1 leaves component 1.. empty
   Xyzz acc = E::identity();
-  if (per == 1) {
-    if (comp == 0 && lane == 0) acc = IO::load_dev_xyzz(partial + 64ull * w);
-  } else {
-    const uint32_t len = half / slices, j0 = slice * len;  // slices <= half, both powers of two
-    for (uint32_t j = j0 + lane; j < j0 + len; j += 64) {
-      uint32_t r, which;
-      if (comp < 2) {
-        r = comp * half + j;
-        which = 0;  // T_r
-      } else {
-        uint32_t i = comp - 2;  // runs whose index has bit i set
-        r = ((j >> i) << (i + 1)) | (1u << i) | (j & ((1u << i) - 1u));
-        which = 32;  // S_r
+  if (slice < slices) {
+    if (per == 1) {
+      if (comp == 0 && lane == 0) acc = IO::load_dev_xyzz(partial + 64ull * w);
+    } else {
+      const uint32_t len = half / slices, j0 = slice * len;  // slices <= half, both powers of two
+      for (uint32_t j = j0 + lane; j < j0 + len; j += 64) {
+        uint32_t r, which;
+        if (comp < 2) {
+          r = comp * half + j;
+          which = 0;  // T_r
+        } else {
+          uint32_t i = comp - 2;  // runs whose index has bit i set
+          r = ((j >> i) << (i + 1)) | (1u << i) | (j & ((1u << i) - 1u));
+          which = 32;  // S_r
+        }
+        acc = E::add(acc, IO::load_dev_xyzz(partial + 64ull * ((uint64_t)w * per + r) + which));
       }
-      acc = E::add(acc, IO::load_dev_xyzz(partial + 64ull * ((uint64_t)w * per + r) + which));
     }
   }
   acc = wave_sum_xyzz<BF>(acc);
   if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      xs[wave][i] = acc.x.l[i];
+      xs[wave][9 + i] = acc.y.l[i];
+      xs[wave][18 + i] = acc.zz.l[i];
+      xs[wave][27 + i] = acc.zzz.l[i];
+    }
+    xs[wave][36] = acc.inf ? 1 : 0;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  Xyzz v = E::identity();
+  if (lane < 4) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      v.x.l[i] = xs[lane][i];
+      v.y.l[i] = xs[lane][9 + i];
+      v.zz.l[i] = xs[lane][18 + i];
+      v.zzz.l[i] = xs[lane][27 + i];
+    }
+    v.inf = xs[lane][36] != 0;
+  }
+  v = wave_sum_xyzz<BF, 2>(v);
+  if (lane == 0) {
     const uint64_t o = (uint64_t)w * gridDim.x + comp;
-    if (slices == 1)
-      IO::store_ark_xyzz(out + 32ull * o, acc);
+    if (gridDim.z == 1)
+      IO::store_ark_xyzz(out + 32ull * o, v);
     else
-      IO::store_dev_xyzz(tmp + 32ull * (o * slices + slice), acc);
+      IO::store_dev_xyzz(tmp + 32ull * (o * gridDim.z + blockIdx.z), v);
   }
 }
 

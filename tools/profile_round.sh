@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profile: kernel-trace stats of the default bench command, then PMC passes (each its own run) of an MSM-only bench.
+# usage: tools/profile_round.sh <outdir under gpurun_out>
+set -e
+O=gpurun_out/$1
+mkdir -p $O
+cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
+# MSM-only command: every k_accum launch is the 2^20 bench MSM, so the stats average is the roofline's kernel time
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_msm -o r -- python3 bench.py --steps 20 --warmup 3 --ipa-log2n 0 > $O/bench_stats_msm.log 2>&1
+tail -1 $O/bench_stats_msm.log | cut -c1-300
+# the default command (adds the IPA prove / verify legs: k_accum launches of many sizes)
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_full -o r -- python3 bench.py --steps 20 --warmup 3 > $O/bench_stats_full.log 2>&1
+tail -1 $O/bench_stats_full.log | cut -c1-200
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d $O/pmc_$name -o p -- python3 bench.py --no-cpu-baseline --ipa-log2n 0 --steps 5 --warmup 2 > $O/pmc_$name.log 2>&1
+  echo "pass $name done"
+done
+find $O -name "*.csv" | head -20
