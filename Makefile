@@ -3,13 +3,15 @@
 #   bulletproofs_amd/lib/libarkbp.so   host side above the ABI: C++ mirror of util::msm, Bp, Bp2aryStep, FiatShamirRng
 #   bulletproofs_amd/lib/libbpchk.so   test-only host build of the device arithmetic headers
 #   oracle/_build/libpasta_oracle.so   test-only CPU restatement of the reference algorithms (Oracle B)
+#   bulletproofs_amd/bin/{msm_bench,test_ipa}   the reference's command-line drivers for this path, over the library
 HIPCC ?= hipcc
 CXX ?= g++
 CC ?= gcc
 CSRC := bulletproofs_amd/csrc
 LIBDIR := bulletproofs_amd/lib
 
-all: $(LIBDIR)/libbpgpu.so $(LIBDIR)/libarkbp.so $(LIBDIR)/libbpchk.so oracle/_build/libpasta_oracle.so
+BINDIR := bulletproofs_amd/bin
+all: $(LIBDIR)/libbpgpu.so $(LIBDIR)/libarkbp.so $(LIBDIR)/libbpchk.so oracle/_build/libpasta_oracle.so $(BINDIR)/msm_bench $(BINDIR)/test_ipa
 
 $(LIBDIR)/libbpgpu.so: $(CSRC)/bpgpu.hip $(CSRC)/kernels.cuh $(CSRC)/curve.cuh $(CSRC)/field.cuh $(CSRC)/host_field.h $(CSRC)/pasta_consts.h include/bpgpu.h
 	@mkdir -p $(LIBDIR)
@@ -27,6 +29,11 @@ oracle/_build/libpasta_oracle.so: oracle/pasta_oracle.c
 	@mkdir -p oracle/_build
 	$(CC) -O3 -march=native -std=c11 -shared -fPIC -pthread $< -o $@
 
+# the reference's two command-line drivers for this path (examples/msm_bench.rs; test_ipa of src/lib.rs:110-135)
+$(BINDIR)/%: examples/%.cpp bulletproofs_amd/host/ark_bp.hpp $(CSRC)/host_field.h $(CSRC)/pasta_consts.h include/bpgpu.h $(LIBDIR)/libbpgpu.so
+	@mkdir -p $(BINDIR)
+	$(CXX) -O2 -std=c++17 $< -o $@ -L$(LIBDIR) -lbpgpu -Wl,-rpath,'$$ORIGIN/../lib'
+
 clean:
-	rm -f $(LIBDIR)/*.so oracle/_build/*.so
+	rm -f $(LIBDIR)/*.so oracle/_build/*.so $(BINDIR)/*
 .PHONY: all clean

@@ -175,7 +175,11 @@ def main():
                        "parallelism": f"point-range shards x{world}, all_gather of 72 B partials" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "kernel": "k_accum (bucket accumulation, mixed XYZZ adds)",
                          "achieved": achieved / 1e12, "peak": mad_peak / 1e12, "unit": "Tmad/s",
-                         "frac": achieved / mad_peak if mad_peak else None, "traffic": None,
+                         "frac": achieved / mad_peak if mad_peak else None,
+                         "traffic": pmc_traffic("k_accum", False) if (args.log2n == 20 and curve == 0 and not args.window) else None,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC of this command (profiles/r01_pmc_summary.csv): "
+                                         "FETCH_SIZE + WRITE_SIZE, raw (64-byte gathers); algorithmic = windows x n x 68 B",
+                         "algorithmic_bytes": W * n * 68,
                          "avg_kernel_ms": phase[3],
                          "note": "algorithmic mads = windows * n * 11 field-mul * 136 mad (SURVEY 8d); peak = measured v_mad_u64_u32 issue rate"},
             "phases_ms": {"digits+hist": phase[0], "scan": phase[1], "scatter": phase[2], "accumulate": phase[3],
@@ -193,6 +197,28 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+
+
+def pmc_traffic(kernel, streaming):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (tools/profile_round.sh -> tools/pmc_summary.py; FETCH_SIZE and WRITE_SIZE are in KiB).  For wide
+    coalesced streaming reads gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM):
+    doubled when `streaming`; left raw for 64-byte gathers, which that note calls uncalibrated.
+    None when the summary is missing."""
+    try:
+        vals = {}
+        for line in open(PMC_SUMMARY):
+            f = line.strip().split(",")
+            if len(f) == 4 and f[0].startswith(kernel) and f[2] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[f[2]] = float(f[3]) * 1024.0
+        if len(vals) != 2:
+            return None
+        return vals["FETCH_SIZE"] * (2.0 if streaming else 1.0) + vals["WRITE_SIZE"]
+    except OSError:
+        return None
 
 
 def scalar_kernels_leg(ffi, curve, log2n=24):
@@ -220,7 +246,9 @@ def scalar_kernels_leg(ffi, curve, log2n=24):
     fold_gbs = n * 96 / (best_fold * 1e-3) / 1e9
     ip_gbs = n * 64 / (best_ip * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "k_fold_scalars", "achieved": fold_gbs, "peak": peak, "unit": "GB/s",
-            "frac": fold_gbs / peak, "traffic": None, "avg_kernel_ms": best_fold,
+            "frac": fold_gbs / peak, "traffic": pmc_traffic("k_fold_scalars", True) if (log2n == 24 and curve == 0) else None,
+            "traffic_note": "bytes per launch, rocprofv3 PMC (profiles/r01_pmc_summary.csv): 2 x FETCH_SIZE + WRITE_SIZE; algorithmic = outputs x 96 B",
+            "avg_kernel_ms": best_fold,
             "outputs": n, "algorithmic_bytes_per_output": 96,
             "k_ip": {"achieved": ip_gbs, "frac": ip_gbs / peak, "kernel_ms": best_ip, "terms": n,
                      "algorithmic_bytes_per_term": 64}}

@@ -12,6 +12,9 @@
 //   util::{powers, scale_vec, sum_vecs, hadamard, hadamard_gp, zero_pad_to_multiple,
 //          zero_intersperse_to_multiple}                    src/util/mod.rs:25-134
 //   KaryBp::{prove_step, verify_step}                      src/proofs/bp_rec_kary.rs:27-190
+//   test_rng, Fp256 / point sampling, sample_from_length   examples/msm_bench.rs:40-44, src/lib.rs:111-118,
+//                                                          src/relations/ipa.rs:28-36,90-97,110-115
+//   util::naive_msm (msm_bench's default algorithm)        src/util/msm.rs:13-24
 #pragma once
 #include <array>
 #include <cstdint>
@@ -155,10 +158,11 @@ class Blake2s {
   }
 };
 
-// ---- rand_chacha ChaCha20Rng behind rand_core's BlockRng (64-word buffer) -------------------
-class ChaCha20Rng {
+// ---- rand_chacha ChaCha{12,20}Rng behind rand_core's BlockRng (64-word buffer) ----------------
+template <int DOUBLE_ROUNDS>
+class ChaChaRng {
  public:
-  explicit ChaCha20Rng(const std::array<uint8_t, 32>& seed) {
+  explicit ChaChaRng(const std::array<uint8_t, 32>& seed) {
     std::memcpy(key_, seed.data(), 32);
     counter_ = 0;
     index_ = 64;
@@ -207,7 +211,7 @@ class ChaCha20Rng {
       x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
       x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
     };
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < DOUBLE_ROUNDS; r++) {
       qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
       qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
     }
@@ -221,6 +225,86 @@ class ChaCha20Rng {
   uint64_t counter_;
   uint32_t buf_[64];
   int index_;
+};
+using ChaCha20Rng = ChaChaRng<10>;  // rand_chacha::ChaChaRng, the Fiat-Shamir generator
+using StdRng = ChaChaRng<6>;        // rand 0.8 StdRng = ChaCha12
+
+// ark_std::test_rng(): StdRng from a fixed seed (examples/msm_bench.rs:40, src/lib.rs:111)
+inline StdRng test_rng() {
+  return StdRng(std::array<uint8_t, 32>{1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0});
+}
+
+// ---- UniformRand for Fp256 and for short-Weierstrass points (ark-ff / ark-ec 0.3) ---------------
+// Fp256::rand: four next_u64 limbs, top bit cleared, accepted iff below the modulus; the accepted limbs
+// ARE the Montgomery representation.  FID: 0 = Pallas base field (= Vesta scalar field), 1 = the other.
+template <int FID, class Rng>
+bpgpu::host::H4 rand_field(Rng& rng) {
+  using C = bpgpu::FieldConsts<FID>;
+  for (;;) {
+    bpgpu::host::H4 x;
+    for (int i = 0; i < 4; i++) x.v[i] = rng.next_u64();
+    x.v[3] &= 0x7fffffffffffffffull;
+    for (int i = 3; i >= 0; i--) {
+      if (x.v[i] < C::P64[i]) return x;
+      if (x.v[i] > C::P64[i]) break;
+    }
+  }
+}
+template <int FID>
+struct FieldSqrt {
+  using HF = bpgpu::host::HF<FID>;
+  using H4 = bpgpu::host::H4;
+  static H4 pow(const H4& a, const uint64_t e[4]) {
+    H4 acc = HF::one();
+    for (int i = 3; i >= 0; i--)
+      for (int b = 63; b >= 0; b--) {
+        acc = HF::sqr(acc);
+        if ((e[i] >> b) & 1) acc = HF::mul(acc, a);
+      }
+    return acc;
+  }
+  // Tonelli-Shanks for p - 1 = 2^32 t (both Pasta fields); false for a non-residue
+  static bool sqrt(const H4& a, H4& root) {
+    using C = bpgpu::FieldConsts<FID>;
+    if (HF::is_zero(a)) { root = a; return true; }
+    uint64_t t[4], half[4];  // t = (p - 1) / 2^32, half = (t - 1) / 2
+    for (int i = 0; i < 4; i++) t[i] = (C::P64[i] >> 32) | (i + 1 < 4 ? C::P64[i + 1] << 32 : 0);
+    for (int i = 0; i < 4; i++) half[i] = (t[i] >> 1) | (i + 1 < 4 ? t[i + 1] << 63 : 0);
+    static const H4 z0 = [&] {  // a 2^32-th root of unity of full order: g^t for the first non-residue g
+      uint64_t e[4];            // (p - 1) / 2
+      for (int i = 0; i < 4; i++) e[i] = (C::P64[i] >> 1) | (i + 1 < 4 ? C::P64[i + 1] << 63 : 0);
+      for (uint64_t g = 2;; g++) {
+        H4 gm = HF::from_u64(g);
+        if (!HF::eq(pow(gm, e), HF::one())) return pow(gm, t);
+      }
+    }();
+    H4 z = z0;
+    H4 w = pow(a, half), x = HF::mul(a, w), b = HF::mul(x, w);
+    int v = 32;
+    while (!HF::eq(b, HF::one())) {
+      int k = 0;
+      H4 b2k = b;
+      while (!HF::eq(b2k, HF::one())) {
+        b2k = HF::sqr(b2k);
+        if (++k == v) return false;
+      }
+      H4 ww = z;
+      for (int j = 0; j < v - k - 1; j++) ww = HF::sqr(ww);
+      z = HF::sqr(ww);
+      b = HF::mul(b, z);
+      x = HF::mul(x, ww);
+      v = k;
+    }
+    root = x;
+    return true;
+  }
+  static bool canon_less(const H4& a, const H4& b) {
+    H4 ca = HF::to_canon(a), cb = HF::to_canon(b);
+    for (int i = 3; i >= 0; i--) {
+      if (ca.v[i] != cb.v[i]) return ca.v[i] < cb.v[i];
+    }
+    return false;
+  }
 };
 
 // ---- ark-marlin 0.3 FiatShamirRng<Blake2s> (src/lib.rs:5) ----------------------------------
@@ -383,6 +467,10 @@ std::vector<G> hadamard_gp(const std::vector<G>& bases, const std::vector<Fr>& s
                               bases.size(), out.empty() ? nullptr : out.data()->v));
   return out;
 }
+// the naive msm (util/msm.rs:13-24, what `msm_bench` runs by default): n independent base.mul(scalar)
+// on the device (hadamard_gp) and the sum of the results; `zip` truncates to the shorter input
+template <int CURVE>
+G naive_msm(const std::vector<G>& bases, const std::vector<Fr>& scalars);
 // sum of group elements (Iterator::sum over G), through the library's point adder
 template <int CURVE>
 G sum_points(const std::vector<G>& v) {
@@ -394,6 +482,14 @@ G sum_points(const std::vector<G>& v) {
   uint64_t out[9];
   check(bpgpu_points_sum(CURVE, xy.data(), v.size(), out));
   return PointOps<CURVE>::from_xy_inf(out);
+}
+template <int CURVE>
+G naive_msm(const std::vector<G>& bases, const std::vector<Fr>& scalars) {
+  const size_t n = bases.size() < scalars.size() ? bases.size() : scalars.size();
+  std::vector<G> prods(n);
+  check(bpgpu_hadamard_points(CURVE, n ? bases.data()->v : nullptr, n ? scalars.data()->v : nullptr, n,
+                              n ? prods.data()->v : nullptr));
+  return sum_points<CURVE>(prods);
 }
 }  // namespace util
 
@@ -448,6 +544,45 @@ struct DeviceGens {
   }
 };
 
+// ---- sampling (UniformRand), in the reference's draw order -------------------------------------
+// G::ScalarField::rand
+template <int CURVE, class Rng>
+Fr rand_scalar(Rng& rng) {
+  Fr r;
+  bpgpu::host::H4 x = rand_field<1 - CURVE>(rng);
+  std::memcpy(r.v, x.v, 32);
+  return r;
+}
+// GroupProjective::rand for y^2 = x^3 + 5 (ark-ec 0.3 short Weierstrass): loop { x = Fq::rand;
+// greatest = rng.gen::<bool>() (top bit of one next_u32); if x^3 + 5 is a square pick y or -y by
+// (y < -y) XOR greatest on canonical integers }; cofactor 1, so Z = 1.
+template <int CURVE, class Rng>
+G rand_point(Rng& rng) {
+  using HF = bpgpu::host::HF<CURVE>;
+  using H4 = bpgpu::host::H4;
+  const H4 five = HF::from_u64(5);
+  for (;;) {
+    const H4 x = rand_field<CURVE>(rng);
+    const bool greatest = (rng.next_u32() >> 31) != 0;
+    H4 y;
+    if (!FieldSqrt<CURVE>::sqrt(HF::add(HF::mul(HF::sqr(x), x), five), y)) continue;
+    const H4 negy = HF::neg(y);
+    const H4 pick = (FieldSqrt<CURVE>::canon_less(y, negy) != greatest) ? y : negy;
+    G g;
+    std::memcpy(g.v, x.v, 32);
+    std::memcpy(g.v + 4, pick.v, 32);
+    std::memcpy(g.v + 8, HF::one().v, 32);
+    return g;
+  }
+}
+// rng.gen::<[u8; 32]>(): one next_u32 per byte (src/lib.rs:117)
+template <class Rng>
+std::array<uint8_t, 32> gen_seed32(Rng& rng) {
+  std::array<uint8_t, 32> s;
+  for (auto& b : s) b = (uint8_t)rng.next_u32();
+  return s;
+}
+
 template <int CURVE>
 G zero_point() {
   uint64_t o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
@@ -474,6 +609,22 @@ struct IpaRelation {
     if (!(commit_for_witness(x.gens, w) == x.result)) throw Panic("assertion failed: commitment");
   }
 };
+
+// IpaInstance::sample_from_length (ipa.rs:28-36,90-97,110-115): a_gens, b_gens, ip_gen, then a, b;
+// the result is commit_for_witness
+template <int CURVE, class Rng>
+std::pair<IpaInstance, IpaWitness> sample_from_length(Rng& rng, size_t length) {
+  IpaInstance x;
+  IpaWitness w;
+  x.gens.vec_size = length;
+  for (size_t i = 0; i < length; i++) x.gens.a_gens.push_back(rand_point<CURVE>(rng));
+  for (size_t i = 0; i < length; i++) x.gens.b_gens.push_back(rand_point<CURVE>(rng));
+  x.gens.ip_gen = rand_point<CURVE>(rng);
+  for (size_t i = 0; i < length; i++) w.a.push_back(rand_scalar<CURVE>(rng));
+  for (size_t i = 0; i < length; i++) w.b.push_back(rand_scalar<CURVE>(rng));
+  x.result = IpaRelation<CURVE>::commit_for_witness(x.gens, w);
+  return {x, w};
+}
 
 // ---- proofs::bp_iter (src/proofs/bp_iter.rs) --------------------------------------------------
 struct BpProof {
