@@ -229,3 +229,38 @@ def pad(mode, v, k):
     lib.arkbp_pad.restype = ctypes.c_long
     m = _check(lib.arkbp_pad(mode, _p(v), c_size_t(len(v)), c_size_t(k), _p(out)))
     return out[:m]
+
+
+def msm_bench_inputs(curve, n):
+    """examples/msm_bench.rs:40-44 over test_rng(): n points (square roots taken on the device), n scalars."""
+    pts, sc = np.zeros((n, 12), np.uint64), np.zeros((n, 4), np.uint64)
+    _check(load().arkbp_sample(curve, 0, c_size_t(n), _p(pts), None, None, _p(sc), None, None))
+    return pts, sc
+
+
+def ipa_inputs(curve, n):
+    """src/lib.rs:111-118: IpaInstance::sample_from_length draws, then the Fiat-Shamir seed."""
+    A, B, q = np.zeros((n, 12), np.uint64), np.zeros((n, 12), np.uint64), np.zeros((1, 12), np.uint64)
+    a, b, seed = np.zeros((n, 4), np.uint64), np.zeros((n, 4), np.uint64), np.zeros(32, np.uint8)
+    _check(load().arkbp_sample(curve, 1, c_size_t(n), _p(A), _p(B), _p(q), _p(a), _p(b), _p(seed)))
+    return A, B, q, a, b, seed.tobytes()
+
+
+def mat_vec_mult(curve, row_ptr, col_idx, vals, vec):
+    """util::mat_vec_mult (src/relations/com_r1cs.rs:43-57) through the C++ mirror."""
+    row_ptr, col_idx = np.ascontiguousarray(row_ptr, np.uint64), np.ascontiguousarray(col_idx, np.uint64)
+    vals, vec = _u64(vals, 4), _u64(vec, 4)
+    out = np.zeros((len(row_ptr) - 1, 4), np.uint64)
+    _check(load().arkbp_mat_mult(curve, 0, _p(row_ptr), _p(col_idx), _p(vals), c_size_t(len(row_ptr) - 1), _p(vec),
+                                 c_size_t(len(vec)), c_size_t(0), _p(out)))
+    return out
+
+
+def vec_mat_mult(curve, vec, row_ptr, col_idx, vals, output_size):
+    """util::vec_mat_mult (src/relations/com_r1cs.rs:67-83) through the C++ mirror."""
+    row_ptr, col_idx = np.ascontiguousarray(row_ptr, np.uint64), np.ascontiguousarray(col_idx, np.uint64)
+    vals, vec = _u64(vals, 4), _u64(vec, 4)
+    out = np.zeros((output_size, 4), np.uint64)
+    _check(load().arkbp_mat_mult(curve, 1, _p(row_ptr), _p(col_idx), _p(vals), c_size_t(len(row_ptr) - 1), _p(vec),
+                                 c_size_t(len(vec)), c_size_t(output_size), _p(out)))
+    return out

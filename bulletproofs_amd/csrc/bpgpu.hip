@@ -158,6 +158,7 @@ struct Ctx {
   DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy, bcount, redtmp;
   // staging for host-buffer entry points
   DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip, fold_plans;
+  DevBuf aux[6];  // sparse products (row pointers, indices, permutation, values, vector, result), point sampling
   Helper helper;
   PinnedBuf h_winsum;  // window sums land here (pinned: the copy is a plain DMA)
 };
@@ -943,6 +944,7 @@ void bpgpu_shutdown(void) {
   for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial, &g_ctx.heavy, &g_ctx.bcount, &g_ctx.redtmp,
                     &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip, &g_ctx.fold_plans})
     b->release();
+  for (DevBuf& b : g_ctx.aux) b.release();
   g_ctx.h_winsum.release();
   g_ctx.helper.stop();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);
@@ -1515,6 +1517,168 @@ int bpgpu_powers(int curve, const uint64_t f[4], uint64_t start, size_t n, uint6
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, g_ctx.st_sc.p, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+// ---- sparse matrix - vector products (Com-R1CS compiler) ----------------------------
+// ptr/idx: compressed rows of the product to run (already validated, 32-bit); perm: value index per entry or null
+static int spmv_run(int curve, const uint32_t* ptr, const uint32_t* idx, const uint32_t* perm, size_t nnz,
+                    const uint64_t* vals, size_t n_out, const uint64_t* vec, size_t vec_len, uint64_t* out) {
+  DevBuf* B = g_ctx.aux;
+  TRY(B[0].ensure((n_out + 1) * 4));
+  TRY(B[1].ensure(nnz * 4 + 4));
+  if (perm) TRY(B[2].ensure(nnz * 4 + 4));
+  TRY(B[3].ensure(nnz * 32 + 32));
+  TRY(B[4].ensure(vec_len * 32 + 32));
+  TRY(B[5].ensure(n_out * 32));
+  hipStream_t st = g_ctx.stream;
+  HIP_TRY(hipMemcpyAsync(B[0].p, ptr, (n_out + 1) * 4, hipMemcpyHostToDevice, st));
+  if (nnz) {
+    HIP_TRY(hipMemcpyAsync(B[1].p, idx, nnz * 4, hipMemcpyHostToDevice, st));
+    if (perm) HIP_TRY(hipMemcpyAsync(B[2].p, perm, nnz * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(B[3].p, vals, nnz * 32, hipMemcpyHostToDevice, st));
+  }
+  if (vec_len) HIP_TRY(hipMemcpyAsync(B[4].p, vec, vec_len * 32, hipMemcpyHostToDevice, st));
+  const uint32_t grid = cdiv((uint64_t)n_out * SPMV_GROUP, 256);
+  const uint32_t* d_perm = perm ? B[2].as<uint32_t>() : nullptr;
+  if (curve == BPGPU_PALLAS)
+    k_spmv<1><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(),
+                                    B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out);
+  else
+    k_spmv<0><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(),
+                                    B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, B[5].p, n_out * 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+// the checks both products share: monotone row pointers starting at 0, sizes inside the kernels' 32-bit indices
+static int spmv_check(const uint64_t* row_ptr, const uint64_t* col_idx, const uint64_t* vals, size_t n_rows, size_t* nnz) {
+  if (n_rows > 0x0fffffffu) return fail(BPGPU_E_ARG, "too many rows");
+  *nnz = 0;
+  if (n_rows == 0) return 0;
+  if (!row_ptr) return fail(BPGPU_E_ARG, "null pointer");
+  if (row_ptr[0] != 0) return fail(BPGPU_E_ARG, "row_ptr[0] must be 0");
+  for (size_t r = 0; r < n_rows; r++)
+    if (row_ptr[r + 1] < row_ptr[r]) return fail(BPGPU_E_ARG, "row_ptr decreases at row %zu", r);
+  *nnz = row_ptr[n_rows];
+  if (*nnz > 0x3fffffffu) return fail(BPGPU_E_ARG, "too many entries");
+  if (*nnz && (!col_idx || !vals)) return fail(BPGPU_E_ARG, "null pointer");
+  return 0;
+}
+
+int bpgpu_mat_vec_mult(int curve, const uint64_t* row_ptr, const uint64_t* col_idx, const uint64_t* vals, size_t n_rows,
+                       const uint64_t* vec, size_t vec_len, uint64_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  size_t nnz = 0;
+  TRY(spmv_check(row_ptr, col_idx, vals, n_rows, &nnz));
+  if (n_rows == 0) return 0;
+  if (!out || (vec_len && !vec)) return fail(BPGPU_E_ARG, "null pointer");
+  if (vec_len > 0x3fffffffu) return fail(BPGPU_E_ARG, "vector too long");
+  std::vector<uint32_t> ptr(n_rows + 1), idx(nnz);
+  for (size_t r = 0; r <= n_rows; r++) ptr[r] = (uint32_t)row_ptr[r];
+  for (size_t e = 0; e < nnz; e++) {
+    if (col_idx[e] >= vec_len)  // assert!(c < &vec.len()), com_r1cs.rs:51
+      return fail(BPGPU_E_ARG, "column index %llu outside the vector (length %zu)", (unsigned long long)col_idx[e], vec_len);
+    idx[e] = (uint32_t)col_idx[e];
+  }
+  return spmv_run(curve, ptr.data(), idx.data(), nullptr, nnz, vals, n_rows, vec, vec_len, out);
+}
+
+int bpgpu_vec_mat_mult(int curve, const uint64_t* vec, size_t vec_len, const uint64_t* row_ptr, const uint64_t* col_idx,
+                       const uint64_t* vals, size_t n_rows, size_t output_size, uint64_t* out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  size_t nnz = 0;
+  TRY(spmv_check(row_ptr, col_idx, vals, n_rows, &nnz));
+  if (vec_len != n_rows)  // assert_eq!(vec.len(), mat.len()), com_r1cs.rs:74
+    return fail(BPGPU_E_ARG, "vector length %zu != matrix rows %zu", vec_len, n_rows);
+  if (output_size > 0x0fffffffu) return fail(BPGPU_E_ARG, "output too long");
+  for (size_t e = 0; e < nnz; e++)
+    if (col_idx[e] >= output_size)  // assert!(mat_cols(mat) <= output_size), com_r1cs.rs:72
+      return fail(BPGPU_E_ARG, "matrix has a column %llu >= output size %zu", (unsigned long long)col_idx[e], output_size);
+  if (output_size == 0) return 0;
+  if (!out || (n_rows && !vec)) return fail(BPGPU_E_ARG, "null pointer");
+  // column-compressed form by a counting sort: entry e of row r becomes (row r, value e) in column col_idx[e]
+  std::vector<uint32_t> ptr(output_size + 1, 0), rows(nnz), perm(nnz);
+  for (size_t e = 0; e < nnz; e++) ptr[col_idx[e] + 1]++;
+  for (size_t c = 0; c < output_size; c++) ptr[c + 1] += ptr[c];
+  {
+    std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
+    for (size_t r = 0; r < n_rows; r++)
+      for (uint64_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+        const uint32_t at = cur[col_idx[e]]++;
+        rows[at] = (uint32_t)r;
+        perm[at] = (uint32_t)e;
+      }
+  }
+  return spmv_run(curve, ptr.data(), rows.data(), perm.data(), nnz, vals, output_size, vec, vec_len, out);
+}
+
+// ---- seed-faithful point sampling ----------------------------------------------------
+extern "C++" {
+template <int BF>
+static void lift_root(LiftArgs* a) {
+  using HF = host::HF<BF>;
+  using C = FieldConsts<BF>;
+  auto pow = [](host::H4 base, const uint64_t e[4]) {
+    host::H4 acc = HF::one();
+    for (int i = 3; i >= 0; i--)
+      for (int b = 63; b >= 0; b--) {
+        acc = HF::sqr(acc);
+        if ((e[i] >> b) & 1) acc = HF::mul(acc, base);
+      }
+    return acc;
+  };
+  uint64_t half[4], t[4];  // (p - 1) / 2 and (p - 1) / 2^32
+  for (int i = 0; i < 4; i++) half[i] = (C::P64[i] >> 1) | (i < 3 ? C::P64[i + 1] << 63 : 0);
+  for (int i = 0; i < 4; i++) t[i] = (C::P64[i] >> 32) | (i < 3 ? C::P64[i + 1] << 32 : 0);
+  for (uint64_t g = 2;; g++) {  // the first non-residue: g^((p-1)/2) = -1
+    host::H4 gm = HF::from_u64(g);
+    if (!HF::eq(pow(gm, half), HF::one())) {
+      host::H4 z = pow(gm, t);
+      memcpy(a->root, z.v, 32);
+      return;
+    }
+  }
+}
+}  // extern "C++"
+
+int bpgpu_curve_lift_x(int curve, const uint64_t* xs, const uint8_t* greatest, size_t m, uint64_t* ys, uint8_t* ok) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (m > 0x3fffffffu) return fail(BPGPU_E_ARG, "m too large");
+  if (m == 0) return 0;
+  if (!xs || !greatest || !ys || !ok) return fail(BPGPU_E_ARG, "null pointer");
+  static LiftArgs args[2];
+  static bool have[2] = {false, false};
+  if (!have[curve]) {
+    if (curve == BPGPU_PALLAS) lift_root<0>(&args[0]); else lift_root<1>(&args[1]);
+    have[curve] = true;
+  }
+  DevBuf* B = g_ctx.aux;
+  TRY(B[0].ensure(m * 32));
+  TRY(B[1].ensure(m));
+  TRY(B[2].ensure(m * 32));
+  TRY(B[3].ensure(m));
+  hipStream_t st = g_ctx.stream;
+  HIP_TRY(hipMemcpyAsync(B[0].p, xs, m * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(B[1].p, greatest, m, hipMemcpyHostToDevice, st));
+  if (curve == BPGPU_PALLAS)
+    k_lift_x<0><<<cdiv(m, 256), 256, 0, st>>>(args[0], B[0].as<uint32_t>(), B[1].as<uint8_t>(), B[2].as<uint32_t>(),
+                                              B[3].as<uint8_t>(), (uint32_t)m);
+  else
+    k_lift_x<1><<<cdiv(m, 256), 256, 0, st>>>(args[1], B[0].as<uint32_t>(), B[1].as<uint8_t>(), B[2].as<uint32_t>(),
+                                              B[3].as<uint8_t>(), (uint32_t)m);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(ys, B[2].p, m * 32, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ok, B[3].p, m, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return 0;
 }
 

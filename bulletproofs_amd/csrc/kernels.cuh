@@ -1360,6 +1360,145 @@ __global__ void __launch_bounds__(256) k_verify_scalars(const uint32_t* __restri
   }
 }
 
+// ---------------------------------------------------------------------------
+// Sparse matrix - vector products of the Com-R1CS compiler: mat_vec_mult and
+// vec_mat_mult, src/relations/com_r1cs.rs:43-57, :67-83, as called at
+// src/reductions/com_r1cs_to_ipa.rs:63-64, 93-99.  One kernel serves both: the matrix arrives in
+// compressed rows,
+//     out[r] = sum_{e in [ptr[r], ptr[r+1])} val[perm ? perm[e] : e] * vec[idx[e]],
+// and the transposed product runs it on the column-compressed form the host derives (perm then points
+// back into the caller's value array, so the 32-byte values are never reordered).  SPMV_GROUP lanes
+// share a row: R1CS rows hold a handful of entries, with a few long ones.  Scalars in ark form.
+// ---------------------------------------------------------------------------
+constexpr uint32_t SPMV_GROUP = 8;
+template <int SF>
+__global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx,
+                                              const uint32_t* __restrict__ perm, const uint32_t* __restrict__ val,
+                                              const uint32_t* __restrict__ vec, uint32_t* __restrict__ out, uint32_t n_rows) {
+  using F = Fp<SF>;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = t / SPMV_GROUP, sub = t % SPMV_GROUP;
+  Fe acc = F::zero();
+  if (r < n_rows) {  // no early return: the shuffles below need every lane of the wave
+    const uint32_t lo = ptr[r], hi = ptr[r + 1];
+    for (uint32_t e = lo + sub; e < hi; e += SPMV_GROUP) {
+      const uint32_t ve = perm ? perm[e] : e;
+      const uint4* pa = reinterpret_cast<const uint4*>(val + 8ull * ve);
+      const uint4* pb = reinterpret_cast<const uint4*>(vec + 8ull * idx[e]);
+      uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+      uint32_t wa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      uint32_t wb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      // (a 2^256)(b 2^256)/2^261 = ab 2^251, fixed up once per row below
+      acc = fe_partial_reduce<SF>(F::add(acc, F::mul(F::unpack(wa), F::unpack(wb))));
+    }
+  }
+#pragma unroll
+  for (uint32_t off = SPMV_GROUP / 2; off >= 1; off >>= 1) {
+    Fe o;
+#pragma unroll
+    for (int k = 0; k < 9; k++) o.l[k] = __shfl_down(acc.l[k], off, 64);
+    acc = fe_partial_reduce<SF>(F::add(acc, o));
+  }
+  if (r < n_rows && sub == 0) {
+    uint32_t w[8];
+    F::store_packed(F::mul(acc, F::from_const(F::C::C256TO261)), w);  // x 2^251 -> x 2^256
+    uint4* po = reinterpret_cast<uint4*>(out + 8ull * r);
+    po[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    po[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Seed-faithful point sampling: the data-parallel half of ark-ec 0.3's
+// GroupProjective::rand for y^2 = x^3 + 5, which examples/msm_bench.rs:41 and
+// src/relations/ipa.rs:28-36 draw their points with.  The host walks the RNG stream (the draws of an
+// attempt -- x by rejection, then one bool -- do not depend on the square root's outcome) and hands
+// every candidate here: ok[i] = 1 iff x^3 + 5 is a square, and then y[i] is the root ark picks,
+// (y < -y) XOR greatest ? y : -y on canonical integers.  Tonelli-Shanks for p - 1 = 2^32 t; `root` is a
+// 2^32-th root of unity of full order (any: the result does not depend on it).  BF = base field.
+// ---------------------------------------------------------------------------
+struct LiftArgs {
+  uint32_t root[8];  // ark form
+};
+template <int BF>
+__global__ void __launch_bounds__(256) k_lift_x(LiftArgs args, const uint32_t* __restrict__ xs,
+                                                const uint8_t* __restrict__ greatest, uint32_t* __restrict__ ys,
+                                                uint8_t* __restrict__ ok, uint32_t n) {
+  using F = Fp<BF>;
+  using C = typename F::C;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  {
+    const uint4* px = reinterpret_cast<const uint4*>(xs + 8ull * i);
+    uint4 a0 = px[0], a1 = px[1];
+    w[0] = a0.x; w[1] = a0.y; w[2] = a0.z; w[3] = a0.w; w[4] = a1.x; w[5] = a1.y; w[6] = a1.z; w[7] = a1.w;
+  }
+  const Fe one = F::one();
+  const Fe x = F::load_ark(w);
+  Fe five = F::carry(F::add(one, one));
+  five = F::carry(F::add(F::carry(F::add(five, five)), one));
+  const Fe a = F::carry(F::add(F::mul(F::sqr(x), x), five));
+  auto is_one = [&](const Fe& v) { return F::is_zero(F::sub(v, one)); };
+  bool good = true;
+  Fe y = F::zero();
+  if (!F::is_zero(a)) {
+    // a^((t-1)/2), t = (p - 1) >> 32 = words 1..7 of p (odd), so (t-1)/2 = t >> 1: 223 bits
+    Fe wv = one;
+    for (int b = 222; b >= 0; b--) {
+      const int bit = b + 1;  // bit of t
+      const uint32_t word = C::P32[1 + (bit >> 5)];
+      wv = F::sqr(wv);
+      if ((word >> (bit & 31)) & 1u) wv = F::mul(wv, a);
+    }
+    y = F::mul(a, wv);        // a^((t+1)/2)
+    Fe b = F::mul(y, wv);     // a^t
+    Fe z = F::load_ark(args.root);
+    int v = 32;
+    for (int guard = 0; guard < 33 && good && !is_one(b); guard++) {
+      int k = 0;
+      Fe b2k = b;
+      while (k < v && !is_one(b2k)) {
+        b2k = F::sqr(b2k);
+        k++;
+      }
+      if (k >= v) {
+        good = false;  // b has order 2^32 or more in a group of order 2^v: not a square
+        break;
+      }
+      Fe ww = z;
+      for (int j = 0; j < v - k - 1; j++) ww = F::sqr(ww);
+      z = F::sqr(ww);
+      b = F::mul(b, z);
+      y = F::mul(y, ww);
+      v = k;
+    }
+    if (good && !is_one(b)) good = false;
+  }
+  uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (good) {
+    // canonical integer of y: montmul(y 2^261, 1) = y; y < p - y  <=>  y <= (p - 1) / 2
+    Fe plain = F::zero();
+    plain.l[0] = 1;
+    uint32_t yi[8];
+    F::store_packed(F::mul(y, plain), yi);
+    bool y_less = true;  // equality cannot happen for y != 0 (p odd); y = 0: both roots are 0
+    for (int k = 7; k >= 0; k--) {
+      const uint32_t h = (C::P32[k] >> 1) | (k < 7 ? C::P32[k + 1] << 31 : 0u);
+      if (yi[k] != h) {
+        y_less = yi[k] < h;
+        break;
+      }
+    }
+    const bool g = greatest[i] != 0;
+    F::store_ark((y_less != g) ? y : F::neg(y), o);
+  }
+  uint4* py = reinterpret_cast<uint4*>(ys + 8ull * i);
+  py[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  py[1] = make_uint4(o[4], o[5], o[6], o[7]);
+  ok[i] = good ? 1 : 0;
+}
+
 // Register-only multiply-add loop: sustained v_mad_u64_u32 issue rate (the integer
 // roofline the MSM and the generator fold are priced against).
 __global__ void __launch_bounds__(256) k_mad_peak(uint32_t* out, uint32_t seed, int iters) {

@@ -46,6 +46,9 @@ SIGNATURES = {
     "bpgpu_hadamard": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_hadamard_points": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_powers": (c_int, [c_int, c_void_p, c_uint64, c_size_t, c_void_p]),
+    "bpgpu_mat_vec_mult": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_vec_mat_mult": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "bpgpu_curve_lift_x": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "bpgpu_ipa_begin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
     "bpgpu_ipa_begin_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
     "bpgpu_ipa_verify_msm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p,
@@ -214,6 +217,36 @@ def powers(curve, f, start, end):
     out = np.zeros((n, 4), dtype=np.uint64)
     _check(load().bpgpu_powers(curve, _ptr(_u64(f)), start, n, _ptr(out)))
     return out
+
+
+def mat_vec_mult(curve, row_ptr, col_idx, vals, vec):
+    """mat_vec_mult (src/relations/com_r1cs.rs:43-57) on a matrix in compressed rows."""
+    row_ptr, col_idx = np.ascontiguousarray(row_ptr, np.uint64), np.ascontiguousarray(col_idx, np.uint64)
+    vals, vec = _u64(vals, 4), _u64(vec, 4)
+    n_rows = len(row_ptr) - 1
+    out = np.zeros((n_rows, 4), dtype=np.uint64)
+    _check(load().bpgpu_mat_vec_mult(curve, _ptr(row_ptr), _ptr(col_idx), _ptr(vals), n_rows, _ptr(vec), len(vec), _ptr(out)))
+    return out
+
+
+def vec_mat_mult(curve, vec, row_ptr, col_idx, vals, output_size):
+    """vec_mat_mult (src/relations/com_r1cs.rs:67-83) on a matrix in compressed rows."""
+    row_ptr, col_idx = np.ascontiguousarray(row_ptr, np.uint64), np.ascontiguousarray(col_idx, np.uint64)
+    vals, vec = _u64(vals, 4), _u64(vec, 4)
+    n_rows = len(row_ptr) - 1
+    out = np.zeros((output_size, 4), dtype=np.uint64)
+    _check(load().bpgpu_vec_mat_mult(curve, _ptr(vec), len(vec), _ptr(row_ptr), _ptr(col_idx), _ptr(vals), n_rows,
+                                     output_size, _ptr(out)))
+    return out
+
+
+def curve_lift_x(curve, xs, greatest):
+    """Candidates (x ark form, greatest) of G::rand -> (ys ark form, ok bytes)."""
+    xs = _u64(xs, 4)
+    g = np.ascontiguousarray(greatest, dtype=np.uint8)
+    ys, ok = np.zeros_like(xs), np.zeros(len(xs), dtype=np.uint8)
+    _check(load().bpgpu_curve_lift_x(curve, _ptr(xs), _ptr(g), len(xs), _ptr(ys), _ptr(ok)))
+    return ys, ok
 
 
 def ipa_verify_msm(curve, a_gens_xyz, b_gens_xyz, ip_gen_xyz, ls_xyz, rs_xyz, challenges, final_a, final_b, d_gens=None):

@@ -491,6 +491,47 @@ G naive_msm(const std::vector<G>& bases, const std::vector<Fr>& scalars) {
                               n ? prods.data()->v : nullptr));
   return sum_points<CURVE>(prods);
 }
+// ---- sparse products of the Com-R1CS compiler (src/relations/com_r1cs.rs:43-83) -------------------
+// ark-relations' Matrix<F>: a list of rows of (value, column) pairs
+using Matrix = std::vector<std::vector<std::pair<Fr, size_t>>>;
+struct Csr {
+  std::vector<uint64_t> row_ptr, col_idx;
+  std::vector<Fr> vals;
+  explicit Csr(const Matrix& mat) : row_ptr(mat.size() + 1, 0) {
+    for (size_t r = 0; r < mat.size(); r++) {
+      row_ptr[r + 1] = row_ptr[r] + mat[r].size();
+      for (const auto& e : mat[r]) {
+        vals.push_back(e.first);
+        col_idx.push_back(e.second);
+      }
+    }
+  }
+};
+inline size_t mat_cols(const Matrix& mat) {  // com_r1cs.rs:59-65
+  size_t m = 0;
+  for (const auto& row : mat)
+    for (const auto& e : row) m = e.second + 1 > m ? e.second + 1 : m;
+  return m;
+}
+// mat_vec_mult(&mat, &vec), com_r1cs.rs:43-57 (panics like the reference's assert!(c < vec.len()))
+template <int CURVE>
+std::vector<Fr> mat_vec_mult(const Matrix& mat, const std::vector<Fr>& vec) {
+  const Csr m(mat);
+  std::vector<Fr> out(mat.size());
+  check(bpgpu_mat_vec_mult(CURVE, m.row_ptr.data(), m.col_idx.data(), m.vals.empty() ? nullptr : m.vals.data()->v, mat.size(),
+                           vec.empty() ? nullptr : vec.data()->v, vec.size(), out.empty() ? nullptr : out.data()->v));
+  return out;
+}
+// vec_mat_mult(&vec, &mat, output_size), com_r1cs.rs:67-83
+template <int CURVE>
+std::vector<Fr> vec_mat_mult(const std::vector<Fr>& vec, const Matrix& mat, size_t output_size) {
+  const Csr m(mat);
+  std::vector<Fr> out(output_size);
+  check(bpgpu_vec_mat_mult(CURVE, vec.empty() ? nullptr : vec.data()->v, vec.size(), m.row_ptr.data(), m.col_idx.data(),
+                           m.vals.empty() ? nullptr : m.vals.data()->v, mat.size(), output_size,
+                           out.empty() ? nullptr : out.data()->v));
+  return out;
+}
 }  // namespace util
 
 // ---- relations (src/relations/ipa.rs) ---------------------------------------------------------
@@ -583,6 +624,48 @@ std::array<uint8_t, 32> gen_seed32(Rng& rng) {
   return s;
 }
 
+// n points by G::rand in one go: the stream is walked on the host (an attempt's draws do not depend on
+// its outcome), the square roots of all candidates are taken on the device (bpgpu_curve_lift_x), and the
+// generator is left exactly where n sequential rand_point calls would leave it.
+template <int CURVE, class Rng>
+std::vector<G> rand_points(Rng& rng, size_t n) {
+  using HF = bpgpu::host::HF<CURVE>;
+  std::vector<G> out;
+  out.reserve(n);
+  while (out.size() < n) {
+    const size_t want = n - out.size(), m = 2 * want + want / 8 + 64;  // about half of the attempts succeed
+    const Rng start = rng;
+    std::vector<bpgpu::host::H4> xs(m), ys(m);
+    std::vector<uint8_t> greatest(m), ok(m);
+    for (size_t i = 0; i < m; i++) {
+      xs[i] = rand_field<CURVE>(rng);
+      greatest[i] = (uint8_t)(rng.next_u32() >> 31);
+    }
+    check(bpgpu_curve_lift_x(CURVE, xs.data()->v, greatest.data(), m, ys.data()->v, ok.data()));
+    size_t used = m;
+    for (size_t i = 0; i < m; i++) {
+      if (!ok[i]) continue;
+      G g;
+      std::memcpy(g.v, xs[i].v, 32);
+      std::memcpy(g.v + 4, ys[i].v, 32);
+      std::memcpy(g.v + 8, HF::one().v, 32);
+      out.push_back(g);
+      if (out.size() == n) {
+        used = i + 1;
+        break;
+      }
+    }
+    if (used < m) {  // rewind to the state right after the last attempt that was needed
+      rng = start;
+      for (size_t i = 0; i < used; i++) {
+        (void)rand_field<CURVE>(rng);
+        (void)rng.next_u32();
+      }
+    }
+  }
+  return out;
+}
+
 template <int CURVE>
 G zero_point() {
   uint64_t o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1};
@@ -617,9 +700,10 @@ std::pair<IpaInstance, IpaWitness> sample_from_length(Rng& rng, size_t length) {
   IpaInstance x;
   IpaWitness w;
   x.gens.vec_size = length;
-  for (size_t i = 0; i < length; i++) x.gens.a_gens.push_back(rand_point<CURVE>(rng));
-  for (size_t i = 0; i < length; i++) x.gens.b_gens.push_back(rand_point<CURVE>(rng));
-  x.gens.ip_gen = rand_point<CURVE>(rng);
+  std::vector<G> gs = rand_points<CURVE>(rng, 2 * length + 1);  // a_gens, b_gens, ip_gen: consecutive draws
+  x.gens.a_gens.assign(gs.begin(), gs.begin() + length);
+  x.gens.b_gens.assign(gs.begin() + length, gs.begin() + 2 * length);
+  x.gens.ip_gen = gs[2 * length];
   for (size_t i = 0; i < length; i++) w.a.push_back(rand_scalar<CURVE>(rng));
   for (size_t i = 0; i < length; i++) w.b.push_back(rand_scalar<CURVE>(rng));
   x.result = IpaRelation<CURVE>::commit_for_witness(x.gens, w);

@@ -359,4 +359,53 @@ long arkbp_pad(int mode, const uint64_t* in, size_t n, size_t k, uint64_t* out) 
     return (int)o.size();
   });
 }
+// the reference's input recipes over test_rng(), points sampled in one batch on the device:
+// mode 0 = examples/msm_bench.rs:40-44 (n points, n scalars; a, b_gens, ip_gen, fs_seed unused),
+// mode 1 = src/lib.rs:111-118 (a_gens, b_gens, ip_gen, a, b, then the 32-byte Fiat-Shamir seed)
+int arkbp_sample(int curve, int mode, size_t n, uint64_t* a_gens, uint64_t* b_gens, uint64_t* ip_gen, uint64_t* a, uint64_t* b,
+                 uint8_t* fs_seed) {
+  return guarded([&] {
+    StdRng rng = test_rng();
+    auto scalars = [&](uint64_t* out) {
+      for (size_t i = 0; i < n; i++) {
+        Fr s = curve == 0 ? rand_scalar<0>(rng) : rand_scalar<1>(rng);
+        std::memcpy(out + 4 * i, s.v, 32);
+      }
+    };
+    if (mode == 0) {
+      std::vector<G> gs = curve == 0 ? rand_points<0>(rng, n) : rand_points<1>(rng, n);
+      if (n) std::memcpy(a_gens, gs.data(), n * 96);
+      scalars(a);
+    } else {
+      std::vector<G> gs = curve == 0 ? rand_points<0>(rng, 2 * n + 1) : rand_points<1>(rng, 2 * n + 1);
+      if (n) std::memcpy(a_gens, gs.data(), n * 96);
+      if (n) std::memcpy(b_gens, gs.data() + n, n * 96);
+      std::memcpy(ip_gen, gs[2 * n].v, 96);
+      scalars(a);
+      scalars(b);
+      std::array<uint8_t, 32> seed = gen_seed32(rng);
+      std::memcpy(fs_seed, seed.data(), 32);
+    }
+    return 0;
+  });
+}
+// util::mat_vec_mult / vec_mat_mult over a Matrix rebuilt from compressed rows (the tests' transport format)
+int arkbp_mat_mult(int curve, int transposed, const uint64_t* row_ptr, const uint64_t* col_idx, const uint64_t* vals,
+                   size_t n_rows, const uint64_t* vec, size_t vec_len, size_t output_size, uint64_t* out) {
+  return guarded([&] {
+    util::Matrix mat(n_rows);
+    for (size_t r = 0; r < n_rows; r++)
+      for (uint64_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+        Fr v;
+        std::memcpy(v.v, vals + 4 * e, 32);
+        mat[r].emplace_back(v, (size_t)col_idx[e]);
+      }
+    std::vector<Fr> x(vec_len);
+    if (vec_len) std::memcpy(x.data(), vec, vec_len * 32);
+    std::vector<Fr> o = transposed ? (curve == 0 ? util::vec_mat_mult<0>(x, mat, output_size) : util::vec_mat_mult<1>(x, mat, output_size))
+                                   : (curve == 0 ? util::mat_vec_mult<0>(mat, x) : util::mat_vec_mult<1>(mat, x));
+    if (!o.empty()) std::memcpy(out, o.data(), o.size() * 32);
+    return (int)o.size();
+  });
+}
 }

@@ -20,11 +20,9 @@ using namespace ark_bp;
 template <int CURVE>
 double msm_bench(size_t n, const std::string& alg, bool print_point) {
   StdRng rng = test_rng();
-  std::vector<G> gs;
+  std::vector<G> gs = rand_points<CURVE>(rng, n);  // square roots of the candidates on the device
   std::vector<Fr> xs;
-  gs.reserve(n);
   xs.reserve(n);
-  for (size_t i = 0; i < n; i++) gs.push_back(rand_point<CURVE>(rng));
   for (size_t i = 0; i < n; i++) xs.push_back(rand_scalar<CURVE>(rng));
   (void)util::msm<CURVE>(gs.data(), n < 64 ? n : 64, xs.data(), n < 64 ? n : 64);  // context warm-up, untimed like the sampling
   auto start = std::chrono::steady_clock::now();

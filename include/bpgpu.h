@@ -136,6 +136,32 @@ int bpgpu_hadamard_points(int curve, const uint64_t* bases_xyz, const uint64_t* 
  * src/util/mod.rs:57-64 (`neg_powers` = powers of the inverse, :66-68); f^0 = 1 for every f. */
 int bpgpu_powers(int curve, const uint64_t f[4], uint64_t start, size_t n, uint64_t* out);
 
+/* ---- sparse matrix - vector products of the Com-R1CS compiler ("next" row f4) --------------------
+ * The reference's Matrix<F> is a list of rows of (value, column) pairs; the shim flattens it into
+ * compressed rows: row r holds entries row_ptr[r] .. row_ptr[r+1] of col_idx / vals (row_ptr has
+ * n_rows + 1 elements, row_ptr[0] = 0; indices are `usize`, hence u64).
+ * bpgpu_mat_vec_mult: out[r] = sum_e vals[e] * vec[col_idx[e]], r < n_rows.  Replaces `mat_vec_mult`,
+ *   reference src/relations/com_r1cs.rs:43-57 (called at src/reductions/com_r1cs_to_ipa.rs:63-64);
+ *   a column index >= vec_len is an error (the reference asserts, :51).
+ * bpgpu_vec_mat_mult: out[c] = sum over entries e of row r with col_idx[e] = c of vals[e] * vec[r],
+ *   c < output_size.  Replaces `vec_mat_mult`, com_r1cs.rs:67-83 (com_r1cs_to_ipa.rs:93-99); errors where
+ *   the reference asserts: vec_len != n_rows (:74), a column >= output_size (:72). */
+int bpgpu_mat_vec_mult(int curve, const uint64_t* row_ptr, const uint64_t* col_idx, const uint64_t* vals,
+                       size_t n_rows, const uint64_t* vec, size_t vec_len, uint64_t* out);
+int bpgpu_vec_mat_mult(int curve, const uint64_t* vec, size_t vec_len, const uint64_t* row_ptr,
+                       const uint64_t* col_idx, const uint64_t* vals, size_t n_rows, size_t output_size,
+                       uint64_t* out);
+
+/* ---- seed-faithful point sampling ("next" row f4) ---------------------------------------------
+ * The data-parallel half of `G::rand` (ark-ec 0.3 GroupProjective::rand for y^2 = x^3 + 5) as the
+ * reference's input recipes use it: examples/msm_bench.rs:41, src/relations/ipa.rs:28-36.  The caller
+ * walks its RNG stream -- per attempt x = Fq::rand (rejection), then one bool; the draws do not depend
+ * on whether the attempt succeeds -- and passes every candidate: xs[i] (ark form), greatest[i] (0/1).
+ * ok[i] = 1 iff x^3 + 5 is a square, and then ys[i] (ark form) is the root ark selects:
+ * (y < -y) XOR greatest ? y : -y, compared as canonical integers.  ys[i] = 0 where ok[i] = 0. */
+int bpgpu_curve_lift_x(int curve, const uint64_t* xs, const uint8_t* greatest, size_t m, uint64_t* ys,
+                       uint8_t* ok);
+
 /* ---- device-resident IPA prover session -------------------------------------
  * Lets `Bp::prove` (reference src/proofs/bp_iter.rs:49-128) keep a, b, A, B in HBM
  * across its log2(N) rounds; Fiat-Shamir stays with the caller between

@@ -233,3 +233,39 @@ def zero_pad_to_multiple(v, k):
 
 def zero_intersperse_to_multiple(v, k):
     return _pad(load().po_zero_intersperse_to_multiple, v, k)
+
+
+# ---- sparse products of the Com-R1CS compiler (src/relations/com_r1cs.rs:43-83) ----------------
+def csr(mat):
+    """list of rows of (value 4 x u64, column) -> row_ptr, col_idx, vals (numpy uint64)."""
+    row_ptr = np.zeros(len(mat) + 1, np.uint64)
+    cols, vals = [], []
+    for r, row in enumerate(mat):
+        row_ptr[r + 1] = row_ptr[r] + np.uint64(len(row))
+        for v, c_ in row:
+            vals.append(np.asarray(v, dtype=np.uint64))
+            cols.append(c_)
+    return (row_ptr, np.asarray(cols, dtype=np.uint64),
+            np.stack(vals).astype(np.uint64) if vals else np.zeros((0, 4), np.uint64))
+
+
+def mat_vec_mult(curve, row_ptr, col_idx, vals, vec):
+    lib = load()
+    n_rows = len(row_ptr) - 1
+    vec, vals = _u64(vec, 4), _u64(vals, 4)
+    o = np.zeros((n_rows, 4), np.uint64)
+    rc = lib.po_mat_vec_mult(curve, _p(row_ptr), _p(col_idx), _p(vals), ctypes.c_size_t(n_rows), _p(vec),
+                             ctypes.c_size_t(len(vec)), _p(o))
+    assert rc == 0, "the reference asserts here"
+    return o
+
+
+def vec_mat_mult(curve, vec, row_ptr, col_idx, vals, output_size):
+    lib = load()
+    n_rows = len(row_ptr) - 1
+    vec, vals = _u64(vec, 4), _u64(vals, 4)
+    o = np.zeros((output_size, 4), np.uint64)
+    rc = lib.po_vec_mat_mult(curve, _p(vec), ctypes.c_size_t(len(vec)), _p(row_ptr), _p(col_idx), _p(vals),
+                             ctypes.c_size_t(n_rows), ctypes.c_size_t(output_size), _p(o))
+    assert rc == 0, "the reference asserts here"
+    return o

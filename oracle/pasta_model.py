@@ -362,6 +362,28 @@ def hadamard_gp(c: Curve, bases: Sequence[Jac], scalars: Sequence[int]) -> List[
     return [jac_mul(c, p, s) for p, s in zip(bases, scalars)]
 
 
+def mat_vec_mult(c: Curve, mat: Sequence[Sequence[Tuple[int, int]]], vec: Sequence[int]) -> List[int]:
+    """ref: src/relations/com_r1cs.rs:43-57 -- rows of (value, column) pairs; result[r] += val * vec[col]."""
+    result = [0] * len(mat)
+    for r, row in enumerate(mat):
+        for val, col in row:
+            assert col < len(vec)
+            result[r] = (result[r] + val * vec[col]) % c.r
+    return result
+
+
+def vec_mat_mult(c: Curve, vec: Sequence[int], mat: Sequence[Sequence[Tuple[int, int]]], output_size: int) -> List[int]:
+    """ref: src/relations/com_r1cs.rs:67-83 -- result[col] += val * vec[r]."""
+    cols = max((col for row in mat for _, col in row), default=-1) + 1
+    assert cols <= output_size
+    assert len(vec) == len(mat)
+    result = [0] * output_size
+    for r, row in enumerate(mat):
+        for val, col in row:
+            result[col] = (result[col] + val * vec[r]) % c.r
+    return result
+
+
 def zero_pad_to_multiple(v: Sequence, k: int, zero):
     """ref: src/util/mod.rs:103-111."""
     out = list(v)
@@ -547,6 +569,17 @@ def rand_point(c: Curve, rng: ChaChaRng) -> Affine:
             continue
         negy = (-y) % c.q
         return (x, y if ((y < negy) != greatest) else negy)
+
+
+def lift_x(c: Curve, x: int, greatest: bool) -> Optional[int]:
+    """ark-ec 0.3 get_point_from_x for y^2 = x^3 + b: None when x^3 + b is not a square, else the root
+    ark selects ((y < -y) XOR greatest ? y : -y on canonical integers) -- the per-candidate half of
+    rand_point above."""
+    y = sqrt_mod((x * x * x + c.b) % c.q, c.q)
+    if y is None:
+        return None
+    negy = (-y) % c.q
+    return y if ((y < negy) != greatest) else negy
 
 
 def msm_bench_inputs(c: Curve, n: int) -> Tuple[List[Affine], List[int]]:

@@ -755,6 +755,43 @@ int po_powers(int curve, const uint64_t f_in[4], uint64_t start, size_t n, uint6
   }
   return 0;
 }
+/* mat_vec_mult, src/relations/com_r1cs.rs:43-57: result[r] += mat_val * vec[c] over the rows' (value, column)
+ * pairs; the matrix comes as compressed rows (row r = entries row_ptr[r] .. row_ptr[r+1]).  Returns -1 where
+ * the reference asserts (c < vec.len()). */
+int po_mat_vec_mult(int curve, const uint64_t* row_ptr, const uint64_t* col_idx, const uint64_t* vals, size_t n_rows,
+                    const uint64_t* vec, size_t vec_len, uint64_t* out) {
+  const field* f = &F[1 - curve];
+  for (size_t r = 0; r < n_rows; r++) {
+    fe acc;
+    memset(&acc, 0, sizeof acc);
+    for (uint64_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+      if (col_idx[e] >= vec_len) return -1;
+      fe t;
+      fe_mul(f, &t, (const fe*)vals + e, (const fe*)vec + col_idx[e]);
+      fe_add(f, &acc, &acc, &t);
+    }
+    ((fe*)out)[r] = acc;
+  }
+  return 0;
+}
+/* vec_mat_mult, src/relations/com_r1cs.rs:67-83: result[c] += mat_val * vec[r]; -1 where the reference asserts
+ * (mat_cols(mat) <= output_size, vec.len() == mat.len()) */
+int po_vec_mat_mult(int curve, const uint64_t* vec, size_t vec_len, const uint64_t* row_ptr, const uint64_t* col_idx,
+                    const uint64_t* vals, size_t n_rows, size_t output_size, uint64_t* out) {
+  const field* f = &F[1 - curve];
+  if (vec_len != n_rows) return -1;
+  for (size_t r = 0; r < n_rows; r++)
+    for (uint64_t e = row_ptr[r]; e < row_ptr[r + 1]; e++)
+      if (col_idx[e] >= output_size) return -1;
+  memset(out, 0, output_size * 32);
+  for (size_t r = 0; r < n_rows; r++)
+    for (uint64_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+      fe t;
+      fe_mul(f, &t, (const fe*)vals + e, (const fe*)vec + r);
+      fe_add(f, (fe*)out + col_idx[e], (fe*)out + col_idx[e], &t);
+    }
+  return 0;
+}
 /* Fr::from(u64) in ark memory form (used by the padding-helper known answers, util/mod.rs:146-203) */
 int po_scalar_from_u64(int curve, uint64_t v, uint64_t out[4]) {
   const uint64_t c[4] = {v, 0, 0, 0};

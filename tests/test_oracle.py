@@ -261,3 +261,45 @@ def test_kary_step_model_invariants(c, n, k):
     if k == 2 and n % 2 == 0:   # k = 2 is the classic round with L = neg cross term, R = pos cross term
         (l, r), i2, w2, x2 = pm.bp_2ary_step_prove(c, inst, wit, pm.FiatShamirRng(seed))
         assert [l] == neg and [r] == pos
+
+
+@pytest.mark.parametrize("c", [pm.PALLAS, pm.VESTA], ids=lambda c: c.name)
+def test_sparse_products_c_matches_model(c):
+    """mat_vec_mult / vec_mat_mult (src/relations/com_r1cs.rs:43-83) restated twice; also the adjoint identity
+    <y, M z> = <y M, z> that ties the two products together."""
+    rng = np.random.default_rng(5)
+    n_rows, n_cols = 40, 30
+    vals = H.rand_scalars(c, 200, 31)
+    mat, k = [], 0
+    for r in range(n_rows):
+        row = []
+        for _ in range(int(rng.integers(0, 6))):
+            row.append((vals[k], int(rng.integers(0, n_cols))))
+            k += 1
+        mat.append(row)
+    mat[3] = []
+    z, y = H.rand_scalars(c, n_cols, 32), H.rand_scalars(c, n_rows, 33)
+    row_ptr, col_idx, v = co.csr([[(H.scalar_abi(c, a), col) for a, col in row] for row in mat])
+    mz = pm.mat_vec_mult(c, mat, z)
+    ym = pm.vec_mat_mult(c, y, mat, n_cols + 2)
+    assert H.scalars_from_abi(c, co.mat_vec_mult(c.curve_id, row_ptr, col_idx, v, H.scalars_abi(c, z))) == mz
+    assert H.scalars_from_abi(c, co.vec_mat_mult(c.curve_id, H.scalars_abi(c, y), row_ptr, col_idx, v, n_cols + 2)) == ym
+    assert ym[n_cols:] == [0, 0] and mz[3] == 0
+    assert pm.ip(c, y, mz) == pm.ip(c, ym[:n_cols], z)
+    # exact small case: [[2@0, 3@2], [5@1]] * (1, 10, 100) = (302, 50); (1, 10) * M = (2, 50, 3)
+    small = [[(2, 0), (3, 2)], [(5, 1)]]
+    assert pm.mat_vec_mult(c, small, [1, 10, 100]) == [302, 50]
+    assert pm.vec_mat_mult(c, [1, 10], small, 3) == [2, 50, 3]
+
+
+@pytest.mark.parametrize("c", [pm.PALLAS, pm.VESTA], ids=lambda c: c.name)
+def test_lift_x_is_the_per_candidate_half_of_rand_point(c):
+    rng, rng2 = pm.test_rng(), pm.test_rng()
+    for _ in range(5):
+        want = pm.rand_point(c, rng)
+        while True:
+            x = c.from_mont_q(pm.rand_field_mont(rng2, c.q))
+            y = pm.lift_x(c, x, rng2.gen_bool())
+            if y is not None:
+                break
+        assert (x, y) == want and pm.is_on_curve(c, want)
