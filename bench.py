@@ -11,9 +11,11 @@ point range (weak scaling: 2^log2n pairs per rank); each step ends with the one 
 exchange the sharded MSM has, an all_gather of the 72-byte partial results over
 RCCL/xGMI followed by their sum (bpgpu_points_sum).  Rank 0 prints ONE JSON line.
 
-Inputs are synthetic: curve points grown from the generator (-1, 2) by repeated
-generator-fold calls with seeded random multipliers (no oracle involved), scalars uniform
-in [0, 2^254).  The cpu_baseline leg (rank 0, N = 1 only) times oracle/pasta_oracle.c --
+Inputs are synthetic.  N = 1: the reference's own recipe (examples/msm_bench.rs:40-44, one
+ark_std::test_rng() stream: n points by G::rand, then n scalars), sampled through the host mirror
+with the square roots taken on the device.  N > 1: every rank grows its own points from the
+generator (-1, 2) by repeated generator-fold calls with seeded random multipliers (no oracle
+involved), scalars uniform in [0, 2^254).  The cpu_baseline leg (rank 0, N = 1 only) times oracle/pasta_oracle.c --
 a restatement of the reference's pippenger_msm -- on a bounded sample of the same bytes
 and checks the GPU result of that sample against it.
 """
@@ -78,6 +80,8 @@ def main():
     ap.add_argument("--ipa-log2n", type=int, default=20, help="log2 N of the secondary IPA-prove measurement (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --one-device rehearses N > 1 ranks on a single GPU")
+    ap.add_argument("--grown-points", action="store_true",
+                    help="N = 1 only: use the per-rank synthetic inputs of the N > 1 runs instead of the msm_bench recipe")
     ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
 
@@ -106,8 +110,16 @@ def main():
     curve = 0 if args.curve == "pallas" else 1
     n = 1 << args.log2n
 
-    pts = synth_points(ffi, curve, n, seed=1000 + rank)
-    sc = synth_scalars(n, seed=2000 + rank)
+    if world == 1 and not args.grown_points:
+        # the reference's own recipe (examples/msm_bench.rs:40-44): one test_rng() stream, n points by G::rand
+        # (square roots of the candidates on the device), then n scalars
+        from bulletproofs_amd import ark_bp
+        pts, sc = ark_bp.msm_bench_inputs(curve, n)
+        recipe = "examples/msm_bench.rs:40-44 (ark_std::test_rng stream: n x G::rand, n x Fr::rand)"
+    else:
+        pts = synth_points(ffi, curve, n, seed=1000 + rank)
+        sc = synth_scalars(n, seed=2000 + rank)
+        recipe = "per-rank seeded: points grown from the generator by random generator folds, scalars uniform below 2^254"
     d_pts = ffi.points_to_device(curve, pts, fmt=0)
     d_sc = ffi.scalars_to_device(sc)
 
@@ -171,7 +183,7 @@ def main():
             "dtype": "u32 limbs (255-bit Montgomery, 9x29-bit, int64 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"2^{args.log2n}-point {args.curve} MSM per GPU, operands resident in HBM",
-                       "points_per_gpu": n, "total_points": world * n, "window_bits": c_bits, "windows": W,
+                       "inputs": recipe, "points_per_gpu": n, "total_points": world * n, "window_bits": c_bits, "windows": W,
                        "parallelism": f"point-range shards x{world}, all_gather of 72 B partials" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "kernel": "k_accum (bucket accumulation, mixed XYZZ adds)",
                          "achieved": achieved / 1e12, "peak": mad_peak / 1e12, "unit": "Tmad/s",

@@ -70,6 +70,32 @@ struct SortPlan {
 };
 constexpr int BIN_PAD = 16;  // bin counters live 64 B apart (one per L2 line)
 
+// Exclusive prefix sum of v over the 1024 threads of a workgroup (total = sum over all of them): wave
+// scans by lane shuffles, then the 16 wave totals through LDS -- two barriers where a 10-step
+// Hillis-Steele scan in LDS takes twenty, and these sort kernels do only 8-16 entries per thread
+// per scan.  wsum: 16 words of LDS, free again after the call's second barrier.
+__device__ __forceinline__ uint32_t wg_excl_scan_1024(uint32_t v, uint32_t* wsum, uint32_t& total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += t;
+  }
+  __syncthreads();  // a previous call's readers are done with wsum
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16; w++) {
+    uint32_t sw = wsum[w];
+    tot += sw;
+    if (w < wave) base += sw;
+  }
+  total = tot;
+  return base + inc - v;
+}
+
 // slot -> (point index, scalar index); returns false past the end
 __device__ __forceinline__ bool slot_lookup(const MsmPlan& plan, uint64_t gid, int& m, uint32_t& pt_idx,
                                             uint32_t& sc_idx) {
@@ -181,7 +207,8 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
                                                        uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ ent_idx,
                                                        uint16_t* __restrict__ ent_fine) {
   __shared__ uint32_t cnt[1024];   // counts, then cursors into buf
-  __shared__ uint32_t gdst[1024];  // scan scratch, then (global position - LDS position) of each bin's run
+  __shared__ uint32_t gdst[1024];  // (global position - LDS position) of each bin's run
+  __shared__ uint32_t wsum[16];
   __shared__ uint32_t buf[PART_TILE];
   __shared__ uint16_t bfine[PART_TILE];
   __shared__ uint16_t bbin[PART_TILE];
@@ -194,24 +221,23 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
   const uint32_t t1 = t0 + PART_TILE < plan.n ? t0 + PART_TILE : plan.n;
   const uint32_t* dw = dig + (uint64_t)wj * plan.n;
   cnt[tid] = 0;
+  // the thread's PART_TILE / 1024 digit words stay in registers for both passes
+  uint32_t dvr[PART_TILE / 1024];
+#pragma unroll
+  for (uint32_t k = 0; k < PART_TILE / 1024; k++) {
+    const uint32_t t = t0 + tid + 1024u * k;
+    dvr[k] = t < t1 ? dw[t] : 0u;
+  }
   __syncthreads();
-  for (uint32_t t = t0 + tid; t < t1; t += 1024) {
-    uint32_t d = dw[t] & 0x7fffffffu;
+#pragma unroll
+  for (uint32_t k = 0; k < PART_TILE / 1024; k++) {
+    uint32_t d = dvr[k] & 0x7fffffffu;
     if (d) atomicAdd(&cnt[(d - 1) >> sp.fine_bits], 1u);
   }
   __syncthreads();
   const uint32_t v = cnt[tid];
-  gdst[tid] = v;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t x = tid >= d ? gdst[tid - d] : 0;
-    __syncthreads();
-    gdst[tid] += x;
-    __syncthreads();
-  }
-  const uint32_t total = gdst[1023];
-  const uint32_t loff = gdst[tid] - v;
-  __syncthreads();
+  uint32_t total;
+  const uint32_t loff = wg_excl_scan_1024(v, wsum, total);
   uint32_t g = 0;
   if (tid < nbw && v) {
     uint32_t b = wj * nbw + tid;
@@ -220,12 +246,13 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
   gdst[tid] = g - loff;
   cnt[tid] = loff;
   __syncthreads();
-  // segment of the first slot; slots advance through at most 3 segments
-  for (uint32_t t = t0 + tid; t < t1; t += 1024) {
-    uint32_t dv = dw[t];
-    uint32_t d = dv & 0x7fffffffu;
+  // segment of the slot; slots advance through at most 3 segments
+#pragma unroll
+  for (uint32_t k = 0; k < PART_TILE / 1024; k++) {
+    const uint32_t dv = dvr[k];
+    const uint32_t d = dv & 0x7fffffffu;
     if (!d) continue;
-    uint32_t r = t;
+    uint32_t r = t0 + tid + 1024u * k;
     int s = 0;
     while (s < 2 && r >= plan.seg[m][s].count) {
       r -= plan.seg[m][s].count;
@@ -286,20 +313,14 @@ __global__ void __launch_bounds__(1024) k_bin_offsets(SortPlan sp, const uint32_
                                                       uint32_t* __restrict__ bcount, uint32_t* __restrict__ offs,
                                                       uint32_t* __restrict__ order, HeavyLists hv) {
   __shared__ uint32_t part[1024];
+  __shared__ uint32_t wsum[16];
   const uint32_t bin = blockIdx.x, tid = threadIdx.x;
   const uint32_t F = 1u << sp.fine_bits;
   const uint32_t bs = bin_start[bin], be = bin_start[bin + 1];
   uint32_t mine = tid < F ? bcount[(uint64_t)bin * F + tid] : 0u;
   if (tid < F) bcount[(uint64_t)bin * F + tid] = 0;  // becomes k_bin_place's cursor
-  part[tid] = mine;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t start = bs + part[tid] - mine;
+  uint32_t bin_total;
+  uint32_t start = bs + wg_excl_scan_1024(mine, wsum, bin_total);
   if (tid < F) offs[(uint64_t)bin * F + tid] = start;
   if (bin == gridDim.x - 1 && tid == 0) offs[(uint64_t)gridDim.x * F] = be;
   // a bucket with more than hv.threshold entries is cut into pieces of HEAVY_PIECE entries that whole
@@ -357,27 +378,29 @@ __global__ void __launch_bounds__(1024) k_bin_place(SortPlan sp, const uint32_t*
                                                     const uint16_t* __restrict__ ent_fine, const uint32_t* __restrict__ offs,
                                                     uint32_t* __restrict__ bcursor, uint32_t* __restrict__ sorted) {
   __shared__ uint32_t cnt[1024];    // counts, then cursors into buf
-  __shared__ uint32_t gdst[1024];   // scan scratch, then (global position - LDS position) of each bucket's run
+  __shared__ uint32_t gdst[1024];   // (global position - LDS position) of each bucket's run
+  __shared__ uint32_t wsum[16];
   __shared__ uint32_t buf[BIN_TILE];
   __shared__ uint16_t bfine[BIN_TILE];
   const uint32_t tid = threadIdx.x, F = 1u << sp.fine_bits;
   uint32_t bin, lo, hi;
   if (!tile_lookup(tile_start, bin_start, sp.nbins, blockIdx.x, bin, lo, hi)) return;
   cnt[tid] = 0;
+  // the thread's BIN_TILE / 1024 fine-bucket numbers stay in registers for both passes
+  uint32_t fr[BIN_TILE / 1024];
+#pragma unroll
+  for (uint32_t k = 0; k < BIN_TILE / 1024; k++) {
+    const uint32_t e = lo + tid + 1024u * k;
+    fr[k] = e < hi ? (uint32_t)ent_fine[e] : 0xffffffffu;
+  }
   __syncthreads();
-  for (uint32_t e = lo + tid; e < hi; e += 1024) atomicAdd(&cnt[ent_fine[e]], 1u);
+#pragma unroll
+  for (uint32_t k = 0; k < BIN_TILE / 1024; k++)
+    if (fr[k] != 0xffffffffu) atomicAdd(&cnt[fr[k]], 1u);
   __syncthreads();
   const uint32_t v = cnt[tid];
-  gdst[tid] = v;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t t = tid >= d ? gdst[tid - d] : 0;
-    __syncthreads();
-    gdst[tid] += t;
-    __syncthreads();
-  }
-  const uint32_t loff = gdst[tid] - v;  // first LDS slot of this bucket's run
-  __syncthreads();
+  uint32_t total;
+  const uint32_t loff = wg_excl_scan_1024(v, wsum, total);  // first LDS slot of this bucket's run
   uint32_t g = 0;
   if (tid < F && v) {
     uint64_t bkt = (uint64_t)bin * F + tid;
@@ -386,10 +409,12 @@ __global__ void __launch_bounds__(1024) k_bin_place(SortPlan sp, const uint32_t*
   gdst[tid] = g - loff;
   cnt[tid] = loff;
   __syncthreads();
-  for (uint32_t e = lo + tid; e < hi; e += 1024) {
-    uint32_t f = ent_fine[e];
+#pragma unroll
+  for (uint32_t k = 0; k < BIN_TILE / 1024; k++) {
+    const uint32_t f = fr[k];
+    if (f == 0xffffffffu) continue;
     uint32_t p = atomicAdd(&cnt[f], 1u);
-    buf[p] = ent_idx[e];
+    buf[p] = ent_idx[lo + tid + 1024u * k];
     bfine[p] = (uint16_t)f;
   }
   __syncthreads();
