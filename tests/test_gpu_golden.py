@@ -44,3 +44,26 @@ def test_gpu_matches_golden(libs, name):
         assert (pf["final_a"] == G.scalars([case["final_a"]])[0]).all()
         assert (pf["final_b"] == G.scalars([case["final_b"]])[0]).all()
         bp.bp_verify(cid, A, B, q, G.points([case["result"]]), pf, seed)
+
+
+@pytest.mark.parametrize("name", ["pallas", "vesta"])
+def test_gpu_matches_golden_next_rows(libs, name):
+    ffi, bp = libs
+    doc = G.load(name)
+    cid, r = doc["curve_id"], doc["next_rows"]
+    k = r["k"]
+    v, y, g = G.scalars(r["v"]), G.scalars(r["y"]), G.points(r["gens"])
+    x = G.scalars([r["x"]])[0]
+    assert (ffi.fold_scalars_kary(cid, v, k, y) == G.scalars(r["fold_scalars_kary"])).all()
+    assert (ffi.fold_points_kary(cid, g, k, y) == G.points(r["fold_points_kary"])).all()
+    assert (ffi.fold_points_kary(cid, g, k, ffi.powers(cid, x, 0, k)) == G.points(r["fold_points_kary_powers"])).all()
+    assert (ffi.powers(cid, x, 5, 12) == G.scalars(r["powers_5_to_12"])).all()
+    hs = G.scalars(r["hadamard_scalars"])
+    assert (ffi.hadamard(cid, v, hs) == G.scalars(r["hadamard"])).all()
+    assert (ffi.hadamard_points(cid, g, hs) == G.points(r["hadamard_gp"])).all()
+    row_ptr, col_idx = np.array(r["mat_row_ptr"], np.uint64), np.array(r["mat_col_idx"], np.uint64)
+    vals = G.scalars(r["mat_vals"])
+    assert (ffi.mat_vec_mult(cid, row_ptr, col_idx, vals, G.scalars(r["z"])) == G.scalars(r["mat_vec"])).all()
+    assert (ffi.vec_mat_mult(cid, G.scalars(r["w"]), row_ptr, col_idx, vals, 7) == G.scalars(r["vec_mat_out7"])).all()
+    ys, ok = ffi.curve_lift_x(cid, G.scalars(r["lift_x"]), np.array(r["lift_greatest"], np.uint8))
+    assert ok.tolist() == r["lift_ok"] and (ys == G.scalars(r["lift_y"])).all()

@@ -75,6 +75,50 @@ def vector_cases(c):
     }
 
 
+def next_row_cases(c):
+    """The "next" rows: k-ary folds, powers, hadamard, hadamard_gp, the sparse products of the
+    Com-R1CS compiler and the per-candidate half of G::rand."""
+    rng = rng_for(f"next-{c.name}")
+    k, ck = 3, 5
+    v = [pm.rand_scalar(c, rng) for _ in range(k * ck)]
+    v[0], v[1] = 0, c.r - 1
+    y = [pm.rand_scalar(c, rng) for _ in range(k)]
+    g = [pm.rand_point(c, rng) for _ in range(k * ck)]
+    g[1] = None
+    g[ck + 2] = g[2]
+    x = pm.rand_scalar(c, rng)
+    xp = pm.powers(c, x, 0, k)
+    hs = [pm.rand_scalar(c, rng) for _ in range(k * ck)]
+    hs[0], hs[3] = 0, 1
+    mat = [[(pm.rand_scalar(c, rng), 0), (pm.rand_scalar(c, rng), 4)], [], [(c.r - 1, 2), (pm.rand_scalar(c, rng), 2), (1, 3)],
+           [(pm.rand_scalar(c, rng), j) for j in range(ck)]]
+    z = [pm.rand_scalar(c, rng) for _ in range(ck)]
+    w = [pm.rand_scalar(c, rng) for _ in range(len(mat))]
+    cand = [c.from_mont_q(pm.rand_field_mont(rng, c.q)) for _ in range(12)]
+    great = [rng.gen_bool() for _ in cand]
+    lifted = [pm.lift_x(c, xx, gg) for xx, gg in zip(cand, great)]
+    fe_hex = lambda vals: [pm.mont_limbs_bytes(c.to_mont_q(t)).hex() for t in vals]
+    jac = lambda ps: [pm.to_jac(p) for p in ps]
+    aff = lambda js: [pm.jac_to_affine(c, j) for j in js]
+    return {
+        "k": k, "ck": ck, "v": sc_hex(c, v), "y": sc_hex(c, y), "x": sc_hex(c, [x])[0],
+        "fold_scalars_kary": sc_hex(c, pm.fold_scalars_kary(c, v, k, y)),
+        "gens": pt_hex(c, g),
+        "fold_points_kary": pt_hex(c, aff(pm.fold_points_kary(c, jac(g), k, y))),
+        "fold_points_kary_powers": pt_hex(c, aff(pm.fold_points_kary(c, jac(g), k, xp))),
+        "powers_5_to_12": sc_hex(c, pm.powers(c, x, 5, 12)),
+        "hadamard_scalars": sc_hex(c, hs),
+        "hadamard": sc_hex(c, pm.hadamard(c, v, hs)),
+        "hadamard_gp": pt_hex(c, aff(pm.hadamard_gp(c, jac(g), hs))),
+        "mat_row_ptr": [0, 2, 2, 5, 5 + ck], "mat_col_idx": [col for row in mat for _, col in row],
+        "mat_vals": sc_hex(c, [val for row in mat for val, _ in row]),
+        "z": sc_hex(c, z), "mat_vec": sc_hex(c, pm.mat_vec_mult(c, mat, z)),
+        "w": sc_hex(c, w), "vec_mat_out7": sc_hex(c, pm.vec_mat_mult(c, w, mat, 7)),
+        "lift_x": fe_hex(cand), "lift_greatest": [int(b) for b in great],
+        "lift_ok": [int(t is not None) for t in lifted], "lift_y": fe_hex([t or 0 for t in lifted]),
+    }
+
+
 def prove_cases(c):
     """Bp::prove transcripts at the reference's own test sizes (src/lib.rs:188,257) with its sampling
     recipe (test_rng stream: a_gens, b_gens, ip_gen, a, b, fs seed), normalise-at-boundary rule."""
@@ -101,7 +145,7 @@ def main():
         doc = {"curve": c.name, "curve_id": c.curve_id,
                "format": "hex of C-ABI bytes: scalar 32 B, jacobian point 96 B (Z = 1, identity = (0,1,0)); Montgomery limbs",
                "generated_by": "tools/gen_golden.py from oracle/pasta_model.py (parity unpinned: no reference vectors exist)",
-               "msm": msm_cases(c), "vectors": vector_cases(c), "bp_prove": prove_cases(c)}
+               "msm": msm_cases(c), "vectors": vector_cases(c), "bp_prove": prove_cases(c), "next_rows": next_row_cases(c)}
         path = os.path.join(OUT, f"{c.name}.json")
         with open(path, "w") as f:
             json.dump(doc, f, indent=0)
