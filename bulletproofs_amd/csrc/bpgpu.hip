@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <functional>
@@ -154,6 +155,7 @@ struct Ctx {
   size_t freeze_len = 1u << 16;  // vectors this short defer the generator fold (0 = never)
   int num_cus = 256;
   float msm_ms[8] = {};
+  uint64_t msm_entries = 0;  // non-zero digits of the last MSM batch = bucket-accumulation additions
   // MSM workspace (grow-only)
   DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy, bcount, redtmp;
   // staging for host-buffer entry points
@@ -233,6 +235,13 @@ int choose_window(uint32_t n) {
   if (g_ctx.window_bits) return g_ctx.window_bits;
   int lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
+  // measured optimum on MI355X for 2^16 .. 2^24 uniform scalars (tools/wsweep.sh; profiles/r01_window_sweep.txt).
+  // The bucket accumulation ends in a tail as long as one of its work items (64 buckets, so about one
+  // bucket's list): wider windows shorten it, until the bucket reduction (a fixed chain of additions
+  // whose length grows with c) costs more than the tail saves.  c = 15 and c = 17 also leave the top
+  // window holding only the carry bit (255 = 15 x 17): half a window of additions less.
+  static const int8_t best[9] = {15, 15, 16, 16, 17, 17, 17, 19, 20};
+  if (lg >= 16 && lg <= 24) return best[lg - 16];
   int c = lg - 4;
   if (c < 2) c = 2;
   if (c > 20) c = 20;
@@ -270,9 +279,11 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const uint32_t B = 1u << (c - 1);
   const uint32_t NB = (uint32_t)plan.M * W * B;
   const uint64_t slots = (uint64_t)plan.M * plan.n;
-  // bucket reduction: runs of S = 2^s buckets, at most 8192 runs per window
-  int s = c - 1 < 2 ? c - 1 : 2;
-  if (NB >= (400u << 10) && c - 1 >= 3) s = 3;  // many buckets: longer runs halve the second stage's work
+  // bucket reduction: runs of S = 2^s buckets, at most 8192 runs per window.  Both stages are bound by the
+  // number of additions they issue (a lone wave already fills its SIMD's issue slots), so longer runs pay
+  // once the second stage's share is large (profiles/r01_window_sweep.txt, second table)
+  int s = c - 1 < 3 ? c - 1 : 3;
+  if (NB >= (800u << 10) && c - 1 >= 4) s = 4;
   if (c - 1 - s > 13) s = c - 1 - 13;
   const uint32_t nruns = NB >> s;
   const uint32_t runs_per_window = B >> s;
@@ -345,10 +356,11 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   HIP_TRY(hipEventRecord(C.ev[4], st));
   k_reduce1<BF><<<cdiv(nruns, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
   {
-    // slices per component: about 2048 waves in all, at least one value per lane
+    // slices per component: about 1024 waves in all (one per SIMD), at least one value per lane.  Every
+    // slice pays a 6-step wave tree on top of its lanes' sums, so more, shorter slices cost more additions
     const uint32_t outputs = (uint32_t)(comps * plan.M * W), half = runs_per_window >> 1;
     uint32_t slices = 1;
-    while (slices < 64 && 2 * slices * outputs <= 2048 && 2 * slices * 64 <= half) slices *= 2;
+    while (slices < 64 && 2 * slices * outputs <= 1024 && 2 * slices * 64 <= half) slices *= 2;
     const uint32_t groups = cdiv(slices, 4);  // a workgroup adds up its four slices itself
     TRY(C.redtmp.ensure((size_t)outputs * groups * 128));
     k_reduce2<BF><<<dim3(comps, plan.M * W, groups), 256, 0, st>>>(
@@ -358,10 +370,18 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
                                                                   groups);
   }
   HIP_TRY(hipEventRecord(C.ev[5], st));
-  TRY(C.h_winsum.ensure((size_t)plan.M * W * comps * 128));
-  HIP_TRY(hipMemcpyAsync(C.h_winsum.p, C.winsum.p, (size_t)plan.M * W * comps * 128, hipMemcpyDeviceToHost, st));
+  const size_t ws_bytes = (size_t)plan.M * W * comps * 128;
+  TRY(C.h_winsum.ensure(ws_bytes + 16));
+  HIP_TRY(hipMemcpyAsync(C.h_winsum.p, C.winsum.p, ws_bytes, hipMemcpyDeviceToHost, st));
+  // total number of sorted entries (bin_start[nbins]) rides along: instrumentation for the roofline
+  HIP_TRY(hipMemcpyAsync((char*)C.h_winsum.p + ws_bytes, bin_start + sp.nbins, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
+  {
+    uint32_t e32;
+    memcpy(&e32, (const char*)C.h_winsum.p + ws_bytes, 4);
+    C.msm_entries = e32;
+  }
   auto t0 = std::chrono::steady_clock::now();
   {
     // Horner tail: one host thread per MSM of the batch (the second one on a helper thread)
@@ -1965,6 +1985,12 @@ int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t o
 int bpgpu_last_msm_timings(float out_ms[8]) {
   if (!out_ms) return fail(BPGPU_E_ARG, "null pointer");
   memcpy(out_ms, g_ctx.msm_ms, sizeof g_ctx.msm_ms);
+  return 0;
+}
+
+int bpgpu_last_msm_entries(uint64_t* entries) {
+  if (!entries) return fail(BPGPU_E_ARG, "null pointer");
+  *entries = g_ctx.msm_entries;
   return 0;
 }
 

@@ -497,30 +497,30 @@ __global__ void __launch_bounds__(256, BP_ACCUM_WAVES) k_accum(const uint32_t* _
       if (!act) hi = lo;
     }
     Xyzz acc = E::identity();
-    // software pipeline: the index two entries ahead and the point one entry ahead are in
-    // flight while the current mixed add runs
+    // software pipeline: the index two entries ahead and the point one entry ahead are in flight
+    // while the current mixed add runs.  The point is unpacked at the BOTTOM of the iteration that
+    // loaded it: nothing at the top of the loop body depends on a pending load, so the only wait
+    // sits behind the mixed add (with the raw words carried across the back edge the compiler put
+    // a wait for the just-issued index load at the top: a full memory latency per entry).
     uint32_t ent = lo < hi ? sorted[lo] : 0u;
     uint32_t ent_n = lo + step < hi ? sorted[lo + step] : 0u;
-    uint4 raw[4];
+    Aff q;
     {
       const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent & 0x7fffffffu));
-      raw[0] = pp[0]; raw[1] = pp[1]; raw[2] = pp[2]; raw[3] = pp[3];
+      const uint4 r0 = pp[0], r1 = pp[1], r2 = pp[2], r3 = pp[3];
+      uint32_t w[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+      q = IO::load_dev_affine(w);
+      if (ent >> 31) q = E::neg(q);
     }
     for (uint32_t e = lo; e < hi; e += step) {
-      uint32_t ent_nn = e + 2 * step < hi ? sorted[e + 2 * step] : 0u;
-      uint4 nxt[4];
-      {
-        const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent_n & 0x7fffffffu));
-        nxt[0] = pp[0]; nxt[1] = pp[1]; nxt[2] = pp[2]; nxt[3] = pp[3];
-      }
-      uint32_t w[16] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w,
-                        raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
-      Aff q = IO::load_dev_affine(w);
-      if (ent >> 31) q = E::neg(q);
+      const uint32_t ent_nn = e + 2 * step < hi ? sorted[e + 2 * step] : 0u;
+      const uint4* pp = reinterpret_cast<const uint4*>(points + 16ull * (ent_n & 0x7fffffffu));
+      const uint4 n0 = pp[0], n1 = pp[1], n2 = pp[2], n3 = pp[3];
       E::madd(acc, q);
-      ent = ent_n;
+      uint32_t w[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
+      q = IO::load_dev_affine(w);
+      if (ent_n >> 31) q = E::neg(q);
       ent_n = ent_nn;
-      raw[0] = nxt[0]; raw[1] = nxt[1]; raw[2] = nxt[2]; raw[3] = nxt[3];
     }
     if (piece) {  // wave-uniform
       acc = wave_sum_xyzz<BF>(acc);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "bpgpu_ipa_free": (None, [c_void_p]),
     "bpgpu_points_sum": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
     "bpgpu_last_msm_timings": (c_int, [POINTER(c_float)]),
+    "bpgpu_last_msm_entries": (c_int, [POINTER(c_uint64)]),
     "bpgpu_last_op_ms": (c_int, [POINTER(c_float)]),
     "bpgpu_measure_mad_peak": (c_int, [POINTER(c_double)]),
 }
@@ -351,6 +352,8 @@ def auto_window_bits(n: int) -> int:
     """Window width the library picks for an n-point MSM (mirror of choose_window in bpgpu.hip;
     reporting only -- the library does not take it from here)."""
     lg = max(0, int(n).bit_length() - 1)
+    if 16 <= lg <= 24:
+        return (15, 15, 16, 16, 17, 17, 17, 19, 20)[lg - 16]   # measured optimum (choose_window's table)
     c = min(20, max(2, lg - 4))
     if lg >= 16:
         best, best_d = -1, 99
@@ -369,6 +372,13 @@ def last_msm_timings():
     out = (c_float * 8)()
     _check(load().bpgpu_last_msm_timings(out))
     return list(out)
+
+
+def last_msm_entries():
+    """Non-zero digits (= bucket-accumulation additions) of the last MSM call."""
+    v = c_uint64()
+    _check(load().bpgpu_last_msm_entries(ctypes.byref(v)))
+    return int(v.value)
 
 
 def last_op_ms():

@@ -229,6 +229,9 @@ int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t o
  * [3] bucket accumulation (k_accum + k_heavy_merge), [4] unused, [5] bucket reduction,
  * [6] host tail (wall), [7] total GPU. */
 int bpgpu_last_msm_timings(float out_ms[8]);
+/* Number of (point, window) pairs with a non-zero digit in the last bpgpu_msm* call (a batch counts both
+ * of its MSMs): the additions the bucket accumulation performed, which bench.py prices the kernel with. */
+int bpgpu_last_msm_entries(uint64_t* entries);
 /* Duration (HIP events on the library's stream) of the kernels of the last inner-product, scalar-fold
  * or generator-fold launch: what bench.py prices against the HBM roofline for the scalar kernels. */
 int bpgpu_last_op_ms(float* ms);
