@@ -153,6 +153,7 @@ struct Ctx {
   hipEvent_t op_ev[2] = {};  // around the last ip / fold launch (bpgpu_last_op_ms)
   int window_bits = 0;
   size_t freeze_len = 1u << 16;  // vectors this short defer the generator fold (0 = never)
+  bool pair_fold = true;         // long rounds fold their generators two rounds at a time (k_fold_joint4)
   int num_cus = 256;
   float msm_ms[8] = {};
   uint64_t msm_entries = 0;  // non-zero digits of the last MSM batch = bucket-accumulation additions
@@ -806,9 +807,14 @@ struct bpgpu_ipa {
   uint32_t* d_sc;
   bool lr_done;
   // deferred generator folding (kernels.cuh, k_frozen_*)
-  size_t freeze_cap;  // room reserved: n0 <= freeze_cap
+  size_t freeze_cap;     // room reserved: n0 <= freeze_cap
+  size_t freeze_thresh;  // vectors this short freeze for good
   bool frozen;
   bool freeze_disabled;
+  // pair folding: the generators of a long round are frozen for ONE round (lazy) and the two pending
+  // challenges are then applied together by k_fold_joint4
+  bool lazy;
+  bool lazy_off;
   size_t n0;  // length at which the generators stopped being folded
   std::vector<std::array<uint64_t, 8>> pending;  // (x, x^-1) of the folds not applied to the points
   // Common factors of the stored generators: the true vectors are muA * A and muB * B.  A fold
@@ -895,11 +901,78 @@ int ipa_fold_generators(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv[
   TRY(rc);
   return fold_points_launch(s->curve, dA, dA, x_inv, x, dB, dB, x, x_inv, 2, n);
 }
+// out[i] = g[i] + s[0] g[i+q] + s[1] g[i+2q] + s[2] g[i+3q] for both generator vectors (multipliers in ark form)
+int fold_joint4_launch(int curve, uint32_t* gA, const uint64_t sA[3][4], uint32_t* gB, const uint64_t sB[3][4], uint32_t q) {
+  if (q == 0) return 0;
+  Ctx& C = g_ctx;
+  static_assert(sizeof(Joint4Plan) * 2 <= 4096, "plan buffer");
+  Joint4Plan plans[2];
+  for (int v = 0; v < 2; v++) {
+    plans[v].len = 0;
+    for (int t = 0; t < 3; t++) {
+      const uint64_t* m = v == 0 ? sA[t] : sB[t];
+      if (curve == BPGPU_PALLAS) TRY(make_monic_plan<0>(m, plans[v].m[t])); else TRY(make_monic_plan<1>(m, plans[v].m[t]));
+      if (plans[v].m[t].len > plans[v].len) plans[v].len = plans[v].m[t].len;
+    }
+  }
+  TRY(C.fold_plans.ensure(4096));
+  HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
+  HIP_TRY(hipMemcpyAsync(C.fold_plans.p, plans, sizeof plans, hipMemcpyHostToDevice, C.stream));
+  HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
+  dim3 grid(cdiv(q, 256), 2);
+  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
+  if (curve == BPGPU_PALLAS)
+    k_fold_joint4<0><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, C.fold_plans.as<Joint4Plan>(), q);
+  else
+    k_fold_joint4<1><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, C.fold_plans.as<Joint4Plan>(), q);
+  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int ipa_replay_pending(bpgpu_ipa* s);
+
+// Both pending challenges (x0 of the round that froze the generators at length n0, x1 of the next) in one
+// pass over the stored generators:  A'' = (x0 x1)^-1 [A_i + x1^2 A_{i+q} + x0^2 A_{i+2q} + (x0 x1)^2 A_{i+3q}],
+// B'' the same with inverted challenges; the leading factors join the common factors.
+template <int SF>
+int ipa_pair_fold_t(bpgpu_ipa* s) {
+  using HF = host::HF<SF>;
+  const uint64_t* c0 = s->pending[0].data();
+  const uint64_t* c1 = s->pending[1].data();
+  if (!are_inverses<SF>(c0, c0 + 4) || !are_inverses<SF>(c1, c1 + 4)) return ipa_replay_pending(s);
+  host::H4 x0, x0i, x1, x1i;
+  memcpy(x0.v, c0, 32);
+  memcpy(x0i.v, c0 + 4, 32);
+  memcpy(x1.v, c1, 32);
+  memcpy(x1i.v, c1 + 4, 32);
+  const host::H4 a1 = HF::sqr(x1), a2 = HF::sqr(x0), b1 = HF::sqr(x1i), b2 = HF::sqr(x0i);
+  const host::H4 a3 = HF::mul(a1, a2), b3 = HF::mul(b1, b2);
+  uint64_t sA[3][4], sB[3][4];
+  memcpy(sA[0], a1.v, 32);
+  memcpy(sA[1], a2.v, 32);
+  memcpy(sA[2], a3.v, 32);
+  memcpy(sB[0], b1.v, 32);
+  memcpy(sB[1], b2.v, 32);
+  memcpy(sB[2], b3.v, 32);
+  TRY(fold_joint4_launch(s->curve, s->d_pts, sA, s->d_pts + 16ull * s->np, sB, (uint32_t)(s->n0 / 4)));
+  const host::H4 fa = HF::mul(x0i, x1i), fb = HF::mul(x0, x1);
+  mu_mul<SF>(s->muA, fa.v);
+  mu_mul<SF>(s->muB, fb.v);
+  s->mu_one = false;
+  s->pending.clear();
+  s->frozen = false;
+  s->lazy = false;
+  return 0;
+}
+int ipa_pair_fold(bpgpu_ipa* s) { return s->curve == BPGPU_PALLAS ? ipa_pair_fold_t<1>(s) : ipa_pair_fold_t<0>(s); }
+
 // stop folding the generators: they stay as they are now (length s->len); the weights start at the
 // common factors
 int ipa_freeze(bpgpu_ipa* s) {
   s->n0 = s->len;
   s->frozen = true;
+  s->lazy = false;
   s->pending.clear();
   const uint32_t half = (uint32_t)s->freeze_cap;
   FoldScalars m = make_fold_scalars(s->muA, s->muB);
@@ -910,8 +983,9 @@ int ipa_freeze(bpgpu_ipa* s) {
   HIP_TRY(hipGetLastError());
   return 0;
 }
-// apply the deferred point folds (export needs the folded generators themselves)
-int ipa_materialise(bpgpu_ipa* s) {
+// apply the deferred point folds one round at a time (s->len is the CURRENT vector length; the stored
+// generators have length n0 and as many folds pending as halvings separate the two)
+int ipa_replay_pending(bpgpu_ipa* s) {
   if (!s->frozen) return 0;
   const size_t final_len = s->len;
   size_t len = s->n0;
@@ -925,7 +999,15 @@ int ipa_materialise(bpgpu_ipa* s) {
   TRY(rc);
   s->pending.clear();
   s->frozen = false;
+  s->lazy = false;
+  return 0;
+}
+// export needs the folded generators themselves; the session folds every round from here on
+int ipa_materialise(bpgpu_ipa* s) {
+  if (!s->frozen) return 0;
+  TRY(ipa_replay_pending(s));
   s->freeze_disabled = true;
+  s->lazy_off = true;
   return 0;
 }
 }  // namespace
@@ -982,6 +1064,11 @@ int bpgpu_set_window_bits(int c) {
 int bpgpu_set_freeze_len(size_t len) {
   if (len > (1u << 24)) return fail(BPGPU_E_ARG, "freeze length too large");
   g_ctx.freeze_len = len;
+  return 0;
+}
+
+int bpgpu_set_pair_fold(int enable) {
+  g_ctx.pair_fold = enable != 0;
   return 0;
 }
 
@@ -1720,7 +1807,10 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
   s->lr_done = false;
   s->d_pts = nullptr;
   s->d_sc = nullptr;
-  s->freeze_cap = np < g_ctx.freeze_len ? np : g_ctx.freeze_len;
+  s->freeze_thresh = np < g_ctx.freeze_len ? np : g_ctx.freeze_len;
+  s->lazy = false;
+  s->lazy_off = !g_ctx.pair_fold || np < 4;
+  s->freeze_cap = s->lazy_off ? s->freeze_thresh : np;  // pair folding freezes at any length
   s->frozen = false;
   s->freeze_disabled = g_ctx.freeze_len == 0;
   s->n0 = 0;
@@ -1774,7 +1864,7 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
       if ((rc = points_in(curve, (uint32_t*)(stg + n * 96), s->d_pts + 16 * np, n, 0)) != 0) break;
       if ((rc = points_in(curve, (uint32_t*)(stg + 2 * n * 96), s->d_pts + 32 * np, 1, 0)) != 0) break;
     }
-    if (np <= s->freeze_cap && !s->freeze_disabled && np > 1 && (rc = ipa_freeze(s)) != 0) break;
+    if (np <= s->freeze_thresh && !s->freeze_disabled && np > 1 && (rc = ipa_freeze(s)) != 0) break;
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(BPGPU_E_HIP, "sync failed");
   } while (0);
   if (rc) {
@@ -1886,6 +1976,13 @@ int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv
   uint32_t* db = s->d_sc + 8ull * np;
   TRY(fold_scalars_launch(s->curve, da, da, fa, db, db, fb, 2, n));
   // A' = x^-1 A_lo + x A_hi;  B' = x B_lo + x^-1 B_hi          (bp_iter.rs:97-104)
+  // pair folding: a long round whose successor is long too leaves its generators alone; the next
+  // round's L, R run over them with weighted scalars and its fold applies both challenges at once
+  if (!s->frozen && !s->lazy_off && s->len >= 4 && s->len / 4 >= (s->freeze_thresh > 1 ? s->freeze_thresh : 1) &&
+      (s->curve == BPGPU_PALLAS ? are_inverses<1>(x, x_inv) : are_inverses<0>(x, x_inv))) {
+    TRY(ipa_freeze(s));
+    s->lazy = true;
+  }
   if (s->frozen) {
     // deferred: the fold only updates the weights of the frozen generators
     const uint32_t n0 = (uint32_t)s->n0;
@@ -1898,12 +1995,13 @@ int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv
     memcpy(ch.data(), x, 32);
     memcpy(ch.data() + 4, x_inv, 32);
     s->pending.push_back(ch);
+    if (s->lazy && s->pending.size() == 2) TRY(ipa_pair_fold(s));
   } else {
     TRY(ipa_fold_generators(s, x, x_inv, n));
   }
   s->len = n;
   s->lr_done = false;
-  if (!s->frozen && !s->freeze_disabled && n > 1 && n <= s->freeze_cap) TRY(ipa_freeze(s));
+  if (!s->frozen && !s->freeze_disabled && n > 1 && n <= s->freeze_thresh) TRY(ipa_freeze(s));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return 0;
 }

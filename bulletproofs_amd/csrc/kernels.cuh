@@ -1194,6 +1194,72 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
   }
 }
 
+// ---------------------------------------------------------------------------
+// Two fold rounds in one pass:  out[i] = g[i] + s1 g[i+q] + s2 g[i+2q] + s3 g[i+3q],  i < q.
+// The prover (bpgpu.hip, "pair folding") skips the generator fold of every other long round -- that
+// round's L and R are MSMs over the unfolded generators with weighted scalars, as in the deferred
+// mode -- and then applies both challenges at once:
+//   x1^-1 (x0^-1 A_i + x0 A_{i+2q}) + x1 (x0^-1 A_{i+q} + x0 A_{i+3q})
+//     = (x0 x1)^-1 [ A_i + x1^2 A_{i+q} + x0^2 A_{i+2q} + x0^2 x1^2 A_{i+3q} ].
+// The three shared multipliers ride ONE doubling chain (128 doublings for three multiplications
+// instead of 3 x 128 when the rounds fold one after the other); digits are Eisenstein units as in
+// k_fold_monic, the unit's x is formed on the fly (one multiplication by zeta or zeta^2) to keep
+// the three points in registers.  out may alias g: a lane reads only indices = i (mod q).
+// ---------------------------------------------------------------------------
+struct Joint4Plan {
+  MonicPlan m[3];  // multipliers of g[i+q], g[i+2q], g[i+3q]
+  int len;         // positions of the longest expansion
+};
+template <int BF>
+__global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_t* o0, const uint32_t* g1, uint32_t* o1,
+                                                     const Joint4Plan* __restrict__ plans, uint32_t q) {
+  using F = Fp<BF>;
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  __shared__ uint32_t tree[512][9];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < q;
+  const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
+  uint32_t* o = blockIdx.y == 0 ? o0 : o1;
+  const Joint4Plan* f = plans + blockIdx.y;
+  Xyzz acc = E::identity();
+  if (active) {
+    const Aff Q0 = IO::load_dev_affine(g + 16ull * (i + q));
+    const Aff Q1 = IO::load_dev_affine(g + 16ull * (i + 2ull * q));
+    const Aff Q2 = IO::load_dev_affine(g + 16ull * (i + 3ull * q));
+    const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
+    const Fe zeta2 = F::sqr(zeta);
+    for (int pos = f->len - 1; pos >= 0; pos--) {
+      acc = E::dbl(acc);
+#pragma unroll 1
+      for (int t = 0; t < 3; t++) {
+        const uint32_t code = (f->m[t].codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;  // wave-uniform
+        const uint32_t sel = code & 3u;
+        if (sel) {
+          Aff p;  // uniform selects, not an indexed array (which would live in scratch)
+          p.x = t == 0 ? Q0.x : (t == 1 ? Q1.x : Q2.x);
+          p.y = t == 0 ? Q0.y : (t == 1 ? Q1.y : Q2.y);
+          p.inf = t == 0 ? Q0.inf : (t == 1 ? Q1.inf : Q2.inf);
+          if (sel != 1) p.x = F::mul(p.x, sel == 2 ? zeta : zeta2);
+          if (code & 8u) p.y = F::carry(F::neg(p.y));
+          E::madd(acc, p);  // skips an identity operand (zero padding)
+        }
+      }
+    }
+    E::madd(acc, IO::load_dev_affine(g + 16ull * i));
+  }
+  const bool fin = active && !acc.inf;
+  const Fe den = fin ? F::mul(acc.zz, acc.zzz) : F::one();
+  const Fe inv = block_inverse_256<BF>(den, tree);
+  if (active) {
+    Aff r;
+    r.inf = !fin;
+    r.x = F::mul(acc.x, F::mul(inv, acc.zzz));
+    r.y = F::mul(acc.y, F::mul(inv, acc.zz));
+    IO::store_dev_affine(o + 16ull * i, r);
+  }
+}
+
 // out[i] = s v[i] for two vectors in one launch (blockIdx.y: v0 with s.lo, v1 with s.hi)
 template <int SF>
 __global__ void __launch_bounds__(256) k_scale_scalars(const uint32_t* __restrict__ v0, uint32_t* __restrict__ o0,

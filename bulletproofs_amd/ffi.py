@@ -24,6 +24,7 @@ SIGNATURES = {
     "bpgpu_last_error": (ctypes.c_char_p, []),
     "bpgpu_set_window_bits": (c_int, [c_int]),
     "bpgpu_set_freeze_len": (c_int, [c_size_t]),
+    "bpgpu_set_pair_fold": (c_int, [c_int]),
     "bpgpu_msm": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_msm_affine": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_ip": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -117,6 +118,10 @@ def shutdown():
 
 def set_window_bits(c: int):
     _check(load().bpgpu_set_window_bits(c))
+
+
+def set_pair_fold(enable: bool):
+    _check(load().bpgpu_set_pair_fold(1 if enable else 0))
 
 
 def set_freeze_len(n: int):

@@ -52,6 +52,9 @@ int bpgpu_set_window_bits(int c);
 /* IPA sessions whose vectors are at most this long defer the generator fold ("deferred
  * folding"; default 2^16, 0 = always fold).  Tuning only: results are identical either way. */
 int bpgpu_set_freeze_len(size_t len);
+/* IPA sessions fold the generators of their long rounds two rounds at a time ("pair
+ * folding"; default on).  Tuning only: results are identical either way. */
+int bpgpu_set_pair_fold(int enable);
 
 /* ---- variable-base MSM ------------------------------------------------------
  * Replaces `pippenger_msm` (= `crate::util::msm`), reference src/util/msm.rs:88-193

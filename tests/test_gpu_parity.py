@@ -225,16 +225,19 @@ def test_msm_full_size_properties(ffi):
     assert int(got[8]) == 0 and (got[:8] == want[:8]).all()
 
 
+@pytest.mark.parametrize("pair", [True, False], ids=["pairfold", "roundfold"])
 @pytest.mark.parametrize("freeze", [0, 2, 8, 64, 1 << 15])
-def test_bp_prove_deferred_fold_equivalence(ffi, freeze):
-    """Deferring the generator fold (frozen generators + challenge-product weights) changes nothing:
-    same L, R, final scalars and exported generators for every freeze length, against the oracle."""
+def test_bp_prove_deferred_fold_equivalence(ffi, freeze, pair):
+    """Deferring the generator fold (frozen generators + challenge-product weights) and folding two rounds
+    at a time (k_fold_joint4) change nothing: same L, R, final scalars and exported generators for every
+    freeze length, with and without pair folding, against the oracle."""
     from oracle import c_oracle as co
     c = pm.PALLAS
     n = 64
     A, B, q, a, b, seed = co.ipa_inputs(0, n)
     ls, rs, ch, fa, fb = co.bp_prove(0, A, B, q, a, b, seed, threads=4)
     ffi.set_freeze_len(freeze)
+    ffi.set_pair_fold(pair)
     try:
         sess = ffi.IpaSession(0, A, B, q, a, b)
         k = 0
@@ -258,10 +261,45 @@ def test_bp_prove_deferred_fold_equivalence(ffi, freeze):
         assert (ga == fa).all() and (gb == fb).all()
     finally:
         ffi.set_freeze_len(1 << 16)
+        ffi.set_pair_fold(True)
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-def test_session_monic_fold_edge_cases(ffi, c):
+@pytest.mark.parametrize("n,freeze", [(2048, 16), (1000, 0), (4096, 256), (512, 2)])
+def test_pair_folding_whole_proofs(ffi, c, n, freeze):
+    """Sizes the oracle still proves in seconds: the proof with pair folding (two challenges applied by one
+    k_fold_joint4 pass, odd and even numbers of long rounds, zero padding at n = 1000) equals the proof
+    with one fold per round and the oracle's."""
+    from oracle import c_oracle as co
+    cid = c.curve_id
+    A, B, q, a, b, seed = co.ipa_inputs(cid, n)
+    np_ = 1 << (n - 1).bit_length()
+    ident = co.normalise(cid, np.zeros((1, 12), np.uint64))
+    Ap, Bp = np.concatenate([A, np.tile(ident, (np_ - n, 1))]), np.concatenate([B, np.tile(ident, (np_ - n, 1))])
+    zs = np.zeros((np_ - n, 4), np.uint64)
+    ls, rs, ch, fa, fb = co.bp_prove(cid, Ap, Bp, q, np.concatenate([a, zs]), np.concatenate([b, zs]), seed, threads=8)
+    ffi.set_freeze_len(freeze)
+    try:
+        for pair in (True, False):
+            ffi.set_pair_fold(pair)
+            sess = ffi.IpaSession(cid, A, B, q, a, b)
+            k = 0
+            while len(sess) > 1:
+                l, r = sess.round_lr()
+                assert (l[:8] == ls[k][:8]).all() and (r[:8] == rs[k][:8]).all(), (pair, k)
+                sess.round_fold(ch[k], co.scalar_inverse(cid, ch[k]))
+                k += 1
+            ga, gb = sess.finish()
+            sess.free()
+            assert (ga == fa).all() and (gb == fb).all(), pair
+    finally:
+        ffi.set_freeze_len(1 << 16)
+        ffi.set_pair_fold(True)
+
+
+@pytest.mark.parametrize("pair", [False, True], ids=["roundfold", "pairfold"])
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_session_monic_fold_edge_cases(ffi, c, pair):
     """The session folds generators as A_lo + x^2 A_hi with the factor x^-1 carried as a scalar
     (k_fold_monic): L, R and the exported generators must equal the reference's
     x^-1 A_lo + x A_hi (bp_iter.rs:97-104) for awkward challenges -- 1, -1, both cube roots of
@@ -284,6 +322,7 @@ def test_session_monic_fold_edge_cases(ffi, c):
     rnd = H.rand_scalars(c, 1, 306)[0]
     pairs = [(1, 1), (c.r - 1, c.r - 1), (lam, lam * lam % c.r), (rnd, pow(rnd, -1, c.r)), (3, 5)]
     ffi.set_freeze_len(0)
+    ffi.set_pair_fold(pair)
     try:
         sess = ffi.IpaSession(c.curve_id, H.jac_abi(c, A), H.jac_abi(c, B), H.jac_abi(c, q), H.scalars_abi(c, a),
                               H.scalars_abi(c, b))
@@ -307,6 +346,7 @@ def test_session_monic_fold_edge_cases(ffi, c):
         sess.free()
     finally:
         ffi.set_freeze_len(1 << 16)
+        ffi.set_pair_fold(True)
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
