@@ -152,7 +152,7 @@ struct Ctx {
   hipEvent_t ev[8] = {};
   hipEvent_t op_ev[2] = {};  // around the last ip / fold launch (bpgpu_last_op_ms)
   int window_bits = 0;
-  size_t freeze_len = 1u << 16;  // vectors this short defer the generator fold (0 = never)
+  size_t freeze_len = 1u << 15;  // vectors this short defer the generator fold (0 = never)
   bool pair_fold = true;         // long rounds fold their generators two rounds at a time (k_fold_joint4)
   int num_cus = 256;
   float msm_ms[8] = {};

@@ -260,7 +260,7 @@ def test_bp_prove_deferred_fold_equivalence(ffi, freeze, pair):
         sess.free()
         assert (ga == fa).all() and (gb == fb).all()
     finally:
-        ffi.set_freeze_len(1 << 16)
+        ffi.set_freeze_len(1 << 15)
         ffi.set_pair_fold(True)
 
 
@@ -293,7 +293,7 @@ def test_pair_folding_whole_proofs(ffi, c, n, freeze):
             sess.free()
             assert (ga == fa).all() and (gb == fb).all(), pair
     finally:
-        ffi.set_freeze_len(1 << 16)
+        ffi.set_freeze_len(1 << 15)
         ffi.set_pair_fold(True)
 
 
@@ -345,7 +345,7 @@ def test_session_monic_fold_edge_cases(ffi, c, pair):
                 assert H.scalars_from_abi(c, ga) == a and H.scalars_from_abi(c, gb) == b
         sess.free()
     finally:
-        ffi.set_freeze_len(1 << 16)
+        ffi.set_freeze_len(1 << 15)
         ffi.set_pair_fold(True)
 
 
