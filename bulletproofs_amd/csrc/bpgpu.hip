@@ -145,6 +145,51 @@ class Helper {
   bool busy_ = false, quit_ = false;
 };
 
+// Large host-to-device copies.  hipMemcpyAsync from pageable memory moves 29 GB/s on the MI355X box, from
+// pinned memory 57 GB/s (tools/h2d_probe.py), and one host core copies 32 GB/s: three worker threads stage
+// 4 MiB chunks into pinned buffers, each chunk's DMA following on the worker's own stream.
+struct Uploader {
+  static constexpr int T = 3, SLOTS = 2;
+  static constexpr size_t CH = 4u << 20, MIN_BYTES = 8u << 20;
+  bool ready = false;
+  void* buf[T][SLOTS] = {};
+  hipStream_t ws[T] = {};
+  hipEvent_t ev[T][SLOTS] = {};
+  hipEvent_t fence = nullptr, done[T] = {};
+  hipError_t init() {
+    if (ready) return hipSuccess;
+    hipError_t e = hipEventCreateWithFlags(&fence, hipEventDisableTiming);
+    for (int w = 0; w < T && e == hipSuccess; w++) {
+      e = hipStreamCreateWithFlags(&ws[w], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&done[w], hipEventDisableTiming);
+      for (int k = 0; k < SLOTS && e == hipSuccess; k++) {
+        e = hipHostMalloc(&buf[w][k], CH, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[w][k], hipEventDisableTiming);
+      }
+    }
+    ready = e == hipSuccess;
+    return e;
+  }
+  void release() {
+    for (int w = 0; w < T; w++) {
+      if (ws[w]) (void)hipStreamSynchronize(ws[w]);
+      for (int k = 0; k < SLOTS; k++) {
+        if (buf[w][k]) (void)hipHostFree(buf[w][k]);
+        if (ev[w][k]) (void)hipEventDestroy(ev[w][k]);
+        buf[w][k] = nullptr;
+        ev[w][k] = nullptr;
+      }
+      if (done[w]) (void)hipEventDestroy(done[w]);
+      if (ws[w]) (void)hipStreamDestroy(ws[w]);
+      done[w] = nullptr;
+      ws[w] = nullptr;
+    }
+    if (fence) (void)hipEventDestroy(fence);
+    fence = nullptr;
+    ready = false;
+  }
+};
+
 struct Ctx {
   bool ready = false;
   int device = 0;
@@ -164,6 +209,7 @@ struct Ctx {
   DevBuf aux[6];  // sparse products (row pointers, indices, permutation, values, vector, result), point sampling
   Helper helper;
   PinnedBuf h_winsum;  // window sums land here (pinned: the copy is a plain DMA)
+  Uploader up;
 };
 
 Ctx g_ctx;
@@ -179,6 +225,43 @@ int check_ready() {
 int check_curve(int curve) {
   if (curve != BPGPU_PALLAS && curve != BPGPU_VESTA) return fail(BPGPU_E_ARG, "unknown curve id %d", curve);
   return 0;
+}
+
+// hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) for a pageable src: ordered after the work
+// already on st and before the work that follows on it.  Returns once src has been read.
+hipError_t upload_async(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  Uploader& U = g_ctx.up;
+  if (bytes < Uploader::MIN_BYTES) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  hipError_t e = U.init();
+  if (e != hipSuccess) return e;
+  if ((e = hipEventRecord(U.fence, st)) != hipSuccess) return e;
+  const size_t nch = (bytes + Uploader::CH - 1) / Uploader::CH;
+  const int device = g_ctx.device;
+  hipError_t err[Uploader::T];
+  std::thread th[Uploader::T];
+  for (int w = 0; w < Uploader::T; w++) {
+    err[w] = hipSuccess;
+    th[w] = std::thread([&, w] {
+      hipError_t r = hipSetDevice(device);
+      if (r == hipSuccess) r = hipStreamWaitEvent(U.ws[w], U.fence, 0);
+      for (size_t k = (size_t)w; k < nch && r == hipSuccess; k += Uploader::T) {
+        const int slot = (int)((k / Uploader::T) % Uploader::SLOTS);
+        const size_t off = k * Uploader::CH, len = bytes - off < Uploader::CH ? bytes - off : Uploader::CH;
+        if ((r = hipEventSynchronize(U.ev[w][slot])) != hipSuccess) break;  // the slot's previous DMA has drained
+        memcpy(U.buf[w][slot], (const char*)src + off, len);
+        if ((r = hipMemcpyAsync((char*)dst + off, U.buf[w][slot], len, hipMemcpyHostToDevice, U.ws[w])) != hipSuccess) break;
+        r = hipEventRecord(U.ev[w][slot], U.ws[w]);
+      }
+      if (r == hipSuccess) r = hipEventRecord(U.done[w], U.ws[w]);
+      err[w] = r;
+    });
+  }
+  for (int w = 0; w < Uploader::T; w++) th[w].join();
+  for (int w = 0; w < Uploader::T; w++) {
+    if (err[w] != hipSuccess) return err[w];
+    if ((e = hipStreamWaitEvent(st, U.done[w], 0)) != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // ---- host tail helpers ------------------------------------------------------
@@ -641,7 +724,7 @@ int fold_points_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64
   // the plans travel through a small device buffer (stream-ordered copy from pinned-by-value staging)
   TRY(C.fold_plans.ensure(sizeof plans));
   HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
-  HIP_TRY(hipMemcpyAsync(C.fold_plans.p, plans, sizeof plans, hipMemcpyHostToDevice, C.stream));
+  HIP_TRY(upload_async(C.fold_plans.p, plans, sizeof plans, C.stream));
   HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
   dim3 grid(cdiv(n, 64), nvec);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
@@ -775,7 +858,7 @@ int fold_monic_pq(int curve, const uint32_t* p0, const uint32_t* q0, uint32_t* o
   }
   TRY(C.fold_plans.ensure(sizeof(FoldPlan) * 2));
   HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
-  HIP_TRY(hipMemcpyAsync(C.fold_plans.p, plans, sizeof plans, hipMemcpyHostToDevice, C.stream));
+  HIP_TRY(upload_async(C.fold_plans.p, plans, sizeof plans, C.stream));
   HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
   dim3 grid(cdiv(n, 256), nvec);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
@@ -917,7 +1000,7 @@ int fold_joint4_launch(int curve, uint32_t* gA, const uint64_t sA[3][4], uint32_
   }
   TRY(C.fold_plans.ensure(4096));
   HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
-  HIP_TRY(hipMemcpyAsync(C.fold_plans.p, plans, sizeof plans, hipMemcpyHostToDevice, C.stream));
+  HIP_TRY(upload_async(C.fold_plans.p, plans, sizeof plans, C.stream));
   HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
   dim3 grid(cdiv(q, 256), 2);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
@@ -1048,6 +1131,7 @@ void bpgpu_shutdown(void) {
     b->release();
   for (DevBuf& b : g_ctx.aux) b.release();
   g_ctx.h_winsum.release();
+  g_ctx.up.release();
   g_ctx.helper.stop();
   for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);
   for (auto& e : g_ctx.op_ev) (void)hipEventDestroy(e);
@@ -1091,7 +1175,7 @@ int bpgpu_dev_upload(void* dptr, const void* host, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_mu);
   TRY(check_ready());
   if (bytes == 0) return 0;
-  HIP_TRY(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(upload_async(dptr, host, bytes, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return 0;
 }
@@ -1113,7 +1197,7 @@ int bpgpu_points_to_device(int curve, const uint64_t* points, size_t n, int fmt,
   if (!points || !d_out) return fail(BPGPU_E_ARG, "null pointer");
   size_t bytes = n * (fmt == 0 ? 96 : 64);
   TRY(g_ctx.st_pts_in.ensure(bytes));
-  HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, points, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(upload_async(g_ctx.st_pts_in.p, points, bytes, g_ctx.stream));
   TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), (uint32_t*)d_out, n, fmt));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return 0;
@@ -1156,8 +1240,8 @@ static int msm_host(int curve, const uint64_t* points, int fmt, const uint64_t* 
     TRY(g_ctx.st_pts_in.ensure(pbytes));
     TRY(g_ctx.st_pts.ensure(n * 64));
     TRY(g_ctx.st_sc.ensure(n * 32));
-    HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, points, pbytes, hipMemcpyHostToDevice, g_ctx.stream));
-    HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(upload_async(g_ctx.st_pts_in.p, points, pbytes, g_ctx.stream));
+    HIP_TRY(upload_async(g_ctx.st_sc.p, scalars, n * 32, g_ctx.stream));
     TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), g_ctx.st_pts.as<uint32_t>(), n, fmt));
   }
   return msm_dispatch(curve, g_ctx.st_pts.as<uint32_t>(), g_ctx.st_sc.as<uint32_t>(), single_plan((uint32_t)n),
@@ -1209,8 +1293,8 @@ int bpgpu_ip(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t
     TRY(g_ctx.st_sc.ensure(2 * n * 32 + 32));
     TRY(g_ctx.st_out.ensure(64));
     if (n) {
-      HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, a, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
-      HIP_TRY(hipMemcpyAsync((uint8_t*)g_ctx.st_sc.p + n * 32, b, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+      HIP_TRY(upload_async(g_ctx.st_sc.p, a, n * 32, g_ctx.stream));
+      HIP_TRY(upload_async((uint8_t*)g_ctx.st_sc.p + n * 32, b, n * 32, g_ctx.stream));
     }
     IpPair p0{0u, (uint32_t)n};
     TRY(ip_launch(curve, g_ctx.st_sc.as<uint32_t>(), p0, p0, 1, (uint32_t)n, g_ctx.st_out.as<uint32_t>(),
@@ -1244,7 +1328,7 @@ int bpgpu_fold_scalars(int curve, const uint64_t* v, size_t n_out, const uint64_
   if (n_out == 0) return 0;
   if (!v || !out || !s_lo || !s_hi) return fail(BPGPU_E_ARG, "null pointer");
   TRY(g_ctx.st_sc.ensure(2 * n_out * 32));
-  HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, v, 2 * n_out * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(upload_async(g_ctx.st_sc.p, v, 2 * n_out * 32, g_ctx.stream));
   FoldScalars f = make_fold_scalars(s_lo, s_hi);
   uint32_t* d = g_ctx.st_sc.as<uint32_t>();
   TRY(fold_scalars_launch(curve, d, d, f, d, d, f, 1, (uint32_t)n_out));
@@ -1277,7 +1361,7 @@ int bpgpu_fold_points(int curve, const uint64_t* g_xyz, size_t n_out, const uint
   size_t n2 = 2 * n_out;
   TRY(g_ctx.st_pts_in.ensure(n2 * 96));
   TRY(g_ctx.st_pts.ensure(n2 * 64));
-  HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, g_xyz, n2 * 96, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(upload_async(g_ctx.st_pts_in.p, g_xyz, n2 * 96, g_ctx.stream));
   TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), g_ctx.st_pts.as<uint32_t>(), n2, 0));
   uint32_t* d = g_ctx.st_pts.as<uint32_t>();
   TRY(fold_points_launch(curve, d, d, s_lo, s_hi, d, d, s_lo, s_hi, 1, (uint32_t)n_out));
@@ -1342,8 +1426,8 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
   hipStream_t st = C.stream;
   uint32_t* dp = C.st_pts.as<uint32_t>();
   uint32_t* ds = C.st_sc.as<uint32_t>();
-  HIP_TRY(hipMemcpyAsync(C.st_ip.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(ds + 8ull * 2 * np, tail.data(), tail.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(upload_async(C.st_ip.p, tab.data(), tab.size() * 8, st));
+  HIP_TRY(upload_async(ds + 8ull * 2 * np, tail.data(), tail.size() * 8, st));
   // generators, zero-padded to np with identity points (bp_iter.rs:137-138)
   if (np > n) {
     HIP_TRY(hipMemsetAsync(dp + 16ull * n, 0, (np - n) * 64, st));
@@ -1362,12 +1446,12 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
     HIP_TRY(hipMemcpyAsync(dp + 16ull * 2 * np, d_q, 64, hipMemcpyDeviceToDevice, st));
   } else {
     if (n) {
-      HIP_TRY(hipMemcpyAsync(stg, a_gens_xyz, n * 96, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(stg + n * 96, b_gens_xyz, n * 96, hipMemcpyHostToDevice, st));
+      HIP_TRY(upload_async(stg, a_gens_xyz, n * 96, st));
+      HIP_TRY(upload_async(stg + n * 96, b_gens_xyz, n * 96, st));
       TRY(points_in(curve, (uint32_t*)stg, dp, n, 0));
       TRY(points_in(curve, (uint32_t*)(stg + n * 96), dp + 16ull * np, n, 0));
     }
-    HIP_TRY(hipMemcpyAsync(stg + 2 * n * 96, ip_gen_xyz, 96, hipMemcpyHostToDevice, st));
+    HIP_TRY(upload_async(stg + 2 * n * 96, ip_gen_xyz, 96, st));
     TRY(points_in(curve, (uint32_t*)(stg + 2 * n * 96), dp + 16ull * 2 * np, 1, 0));
     so = (2 * n + 1) * 96;
   }
@@ -1378,7 +1462,7 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
       memcpy(&lr[(2 * j) * 12], ls_xyz + 12 * j, 96);
       memcpy(&lr[(2 * j + 1) * 12], rs_xyz + 12 * j, 96);
     }
-    HIP_TRY(hipMemcpyAsync(stg + so, lr.data(), 2 * k * 96, hipMemcpyHostToDevice, st));
+    HIP_TRY(upload_async(stg + so, lr.data(), 2 * k * 96, st));
     HIP_TRY(hipStreamSynchronize(st));  // lr, tab and tail live on this frame
     TRY(points_in(curve, (uint32_t*)(stg + so), dp + 16ull * (2 * np + 1), 2 * k, 0));
   } else {
@@ -1450,7 +1534,7 @@ int fold_scalars_kary_launch(int curve, const uint32_t* d_v, size_t ck, size_t k
     return 0;
   }
   TRY(C.st_ip.ensure(k * 32));
-  HIP_TRY(hipMemcpyAsync(C.st_ip.p, y, k * 32, hipMemcpyHostToDevice, C.stream));
+  HIP_TRY(upload_async(C.st_ip.p, y, k * 32, C.stream));
   uint32_t gx = cdiv(ck, 256);
   const uint32_t cap = (uint32_t)C.num_cus * 16;
   if (gx > cap) gx = cap;
@@ -1510,7 +1594,7 @@ int bpgpu_fold_scalars_kary(int curve, const uint64_t* v, size_t ck, size_t k, c
   if (ck == 0) return 0;
   if (!out || (k && (!v || !y))) return fail(BPGPU_E_ARG, "null pointer");
   TRY(g_ctx.st_sc.ensure((k ? k : 1) * ck * 32));
-  if (k) HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, v, k * ck * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  if (k) HIP_TRY(upload_async(g_ctx.st_sc.p, v, k * ck * 32, g_ctx.stream));
   uint32_t* d = g_ctx.st_sc.as<uint32_t>();
   TRY(fold_scalars_kary_launch(curve, d, ck, k, y, d));
   HIP_TRY(hipMemcpyAsync(out, d, ck * 32, hipMemcpyDeviceToHost, g_ctx.stream));
@@ -1546,7 +1630,7 @@ int bpgpu_fold_points_kary(int curve, const uint64_t* g_xyz, size_t ck, size_t k
   uint32_t* d = g_ctx.st_pts.as<uint32_t>();
   uint32_t* d_o = d + 16ull * tot;
   if (tot) {
-    HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, g_xyz, tot * 96, hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(upload_async(g_ctx.st_pts_in.p, g_xyz, tot * 96, g_ctx.stream));
     TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), d, tot, 0));
   }
   TRY(fold_points_kary_launch(curve, d, ck, k, y, d_o));
@@ -1565,8 +1649,8 @@ int bpgpu_hadamard(int curve, const uint64_t* a, const uint64_t* b, size_t n, ui
   if (!a || !b || !out) return fail(BPGPU_E_ARG, "null pointer");
   TRY(g_ctx.st_sc.ensure(2 * n * 32));
   uint32_t* d = g_ctx.st_sc.as<uint32_t>();
-  HIP_TRY(hipMemcpyAsync(d, a, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
-  HIP_TRY(hipMemcpyAsync(d + 8ull * n, b, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(upload_async(d, a, n * 32, g_ctx.stream));
+  HIP_TRY(upload_async(d + 8ull * n, b, n * 32, g_ctx.stream));
   uint32_t gx = cdiv(n, 256);
   const uint32_t cap = (uint32_t)g_ctx.num_cus * 16;
   if (gx > cap) gx = cap;
@@ -1590,8 +1674,8 @@ int bpgpu_hadamard_points(int curve, const uint64_t* bases_xyz, const uint64_t* 
   TRY(g_ctx.st_pts_in.ensure(n * 96));
   TRY(g_ctx.st_pts.ensure(n * 64));
   TRY(g_ctx.st_sc.ensure(n * 32));
-  HIP_TRY(hipMemcpyAsync(g_ctx.st_pts_in.p, bases_xyz, n * 96, hipMemcpyHostToDevice, g_ctx.stream));
-  HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, scalars, n * 32, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(upload_async(g_ctx.st_pts_in.p, bases_xyz, n * 96, g_ctx.stream));
+  HIP_TRY(upload_async(g_ctx.st_sc.p, scalars, n * 32, g_ctx.stream));
   uint32_t* d = g_ctx.st_pts.as<uint32_t>();
   TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), d, n, 0));
   if (curve == BPGPU_PALLAS)
@@ -1639,13 +1723,13 @@ static int spmv_run(int curve, const uint32_t* ptr, const uint32_t* idx, const u
   TRY(B[4].ensure(vec_len * 32 + 32));
   TRY(B[5].ensure(n_out * 32));
   hipStream_t st = g_ctx.stream;
-  HIP_TRY(hipMemcpyAsync(B[0].p, ptr, (n_out + 1) * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(upload_async(B[0].p, ptr, (n_out + 1) * 4, st));
   if (nnz) {
-    HIP_TRY(hipMemcpyAsync(B[1].p, idx, nnz * 4, hipMemcpyHostToDevice, st));
-    if (perm) HIP_TRY(hipMemcpyAsync(B[2].p, perm, nnz * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(B[3].p, vals, nnz * 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(upload_async(B[1].p, idx, nnz * 4, st));
+    if (perm) HIP_TRY(upload_async(B[2].p, perm, nnz * 4, st));
+    HIP_TRY(upload_async(B[3].p, vals, nnz * 32, st));
   }
-  if (vec_len) HIP_TRY(hipMemcpyAsync(B[4].p, vec, vec_len * 32, hipMemcpyHostToDevice, st));
+  if (vec_len) HIP_TRY(upload_async(B[4].p, vec, vec_len * 32, st));
   const uint32_t grid = cdiv((uint64_t)n_out * SPMV_GROUP, 256);
   const uint32_t* d_perm = perm ? B[2].as<uint32_t>() : nullptr;
   if (curve == BPGPU_PALLAS)
@@ -1774,8 +1858,8 @@ int bpgpu_curve_lift_x(int curve, const uint64_t* xs, const uint8_t* greatest, s
   TRY(B[2].ensure(m * 32));
   TRY(B[3].ensure(m));
   hipStream_t st = g_ctx.stream;
-  HIP_TRY(hipMemcpyAsync(B[0].p, xs, m * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(B[1].p, greatest, m, hipMemcpyHostToDevice, st));
+  HIP_TRY(upload_async(B[0].p, xs, m * 32, st));
+  HIP_TRY(upload_async(B[1].p, greatest, m, st));
   if (curve == BPGPU_PALLAS)
     k_lift_x<0><<<cdiv(m, 256), 256, 0, st>>>(args[0], B[0].as<uint32_t>(), B[1].as<uint8_t>(), B[2].as<uint32_t>(),
                                               B[3].as<uint8_t>(), (uint32_t)m);
@@ -1838,8 +1922,8 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
       break;
     }
     if (n) {
-      if (hipMemcpyAsync(s->d_sc, a, n * 32, hipMemcpyHostToDevice, st) != hipSuccess ||
-          hipMemcpyAsync(s->d_sc + 8 * np, b, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) {
+      if (upload_async(s->d_sc, a, n * 32, st) != hipSuccess ||
+          upload_async(s->d_sc + 8 * np, b, n * 32, st) != hipSuccess) {
         rc = fail(BPGPU_E_HIP, "upload failed");
         break;
       }
@@ -1854,9 +1938,9 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
     } else {
       if ((rc = g_ctx.st_pts_in.ensure((2 * n + 1) * 96)) != 0) break;
       uint8_t* stg = (uint8_t*)g_ctx.st_pts_in.p;
-      if ((n && (hipMemcpyAsync(stg, a_gens_xyz, n * 96, hipMemcpyHostToDevice, st) != hipSuccess ||
-                 hipMemcpyAsync(stg + n * 96, b_gens_xyz, n * 96, hipMemcpyHostToDevice, st) != hipSuccess)) ||
-          hipMemcpyAsync(stg + 2 * n * 96, ip_gen_xyz, 96, hipMemcpyHostToDevice, st) != hipSuccess) {
+      if ((n && (upload_async(stg, a_gens_xyz, n * 96, st) != hipSuccess ||
+                 upload_async(stg + n * 96, b_gens_xyz, n * 96, st) != hipSuccess)) ||
+          upload_async(stg + 2 * n * 96, ip_gen_xyz, 96, st) != hipSuccess) {
         rc = fail(BPGPU_E_HIP, "upload failed");
         break;
       }
