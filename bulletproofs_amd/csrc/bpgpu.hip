@@ -315,7 +315,7 @@ host::HPoint<BF> horner(const uint32_t* winsums, int W, int c, int s, int nbits)
 // handful, its few buckets each collect a large share of all points (handled by the heavy-bucket
 // path, but their bin is sorted by a single workgroup), so among the widths next to log2 n - 4
 // prefer one whose top window is well populated.
-int choose_window(uint32_t n) {
+int choose_window(uint32_t n, int M) {
   if (g_ctx.window_bits) return g_ctx.window_bits;
   int lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
@@ -326,6 +326,11 @@ int choose_window(uint32_t n) {
   // window holding only the carry bit (255 = 15 x 17): half a window of additions less.
   static const int8_t best[9] = {15, 15, 16, 16, 17, 17, 17, 19, 20};
   if (lg >= 16 && lg <= 24) return best[lg - 16];
+  // below 2^16 an MSM is a chain of latencies: short lists (about one entry per two buckets) win until the
+  // bucket reduction, twice the work in a batch of two, pushes back (profiles/r01_window_sweep.txt: single
+  // MSM of 2^15: c = 15 0.38 ms, c = 13 0.45 ms; the prover's short rounds, two MSMs of 2^15 non-zero
+  // scalars: c = 13 0.65 ms, c = 15 0.76 ms per round)
+  if (lg >= 5 && lg <= 15) return M > 1 ? lg - 2 : lg;
   int c = lg - 4;
   if (c < 2) c = 2;
   if (c > 20) c = 20;
@@ -356,7 +361,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     out[m][8] = 1;
   }
   if (plan.n == 0) return 0;
-  const int c = choose_window(plan.n);
+  const int c = choose_window(plan.n_eff ? plan.n_eff : plan.n, plan.M);
   const int W = (256 + c - 1) / c;
   plan.c = c;
   plan.W = W;
@@ -401,7 +406,15 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   // heavy-bucket lists: at most entries/HEAVY_T heavy buckets and entries/HEAVY_PIECE + that many pieces
   const uint64_t entries = slots * W;
   const uint64_t mean_len = entries / NB;
-  const uint32_t heavy_t = (uint32_t)(4 * mean_len > HEAVY_T_MIN ? 4 * mean_len : HEAVY_T_MIN);
+  // A single lane walks a list of at most heavy_t entries; longer lists are cut into wave-cooperative pieces.
+  // The floor follows the work there is per lane: in a small MSM (the prover's short rounds) one list of 127
+  // entries -- the top window's carry-only bucket -- kept a lane busy for 0.45 ms, longer than the rest of
+  // the kernel (tools/msm_var_probe.py: 0.18 vs 0.54 ms depending on which side of 128 that bucket fell).
+  const uint64_t lanes = (uint64_t)C.num_cus * 4 * BP_ACCUM_WAVES * 64;
+  uint64_t floor_t = 4 * entries / lanes;
+  if (floor_t < 32) floor_t = 32;
+  if (floor_t > HEAVY_T_MIN) floor_t = HEAVY_T_MIN;
+  const uint32_t heavy_t = (uint32_t)(4 * mean_len > floor_t ? 4 * mean_len : floor_t);
   const size_t max_heavy = (size_t)(entries / heavy_t) + 1, max_pieces = (size_t)(entries / HEAVY_PIECE) + max_heavy;
   TRY(C.heavy.ensure((3 * max_heavy + 2 * max_pieces + 32 * max_pieces) * 4));
   HeavyLists hv;
@@ -2005,6 +2018,7 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
                                                                 n0, n);
     HIP_TRY(hipGetLastError());
     plan.n = 2 * n0 + 1;
+    plan.n_eff = n0 + 1;  // half of the weighted scalars are zero by construction (k_frozen_scalars)
     plan.seg[0][0] = MsmSeg{0u, fs, n0};
     plan.seg[0][1] = MsmSeg{np, fs + n0, n0};
     plan.seg[0][2] = MsmSeg{2 * np, 2 * np, 1};

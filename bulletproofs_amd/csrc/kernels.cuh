@@ -29,6 +29,7 @@ struct MsmPlan {
   int W;       // windows per MSM
   int c;       // window width in bits; digits are signed, |d| <= 2^(c-1)
   uint32_t n;  // slots per MSM (sum of its segment counts)
+  uint32_t n_eff;  // slots whose scalar can be non-zero, if the caller knows (0 = n): sizes the windows
   MsmSeg seg[2][3];
 };
 
