@@ -225,6 +225,31 @@ def test_msm_full_size_properties(ffi):
     assert int(got[8]) == 0 and (got[:8] == want[:8]).all()
 
 
+def test_msm_2_24_sharded_like_eight_gpus(ffi):
+    """BASELINE config 3 on one GPU: 2^24 pairs by the reference's msm_bench recipe (examples/msm_bench.rs:40-44,
+    square roots on the device), cut into the eight contiguous point ranges the ranks of one node own
+    (bulletproofs_amd/sharded.py); the sum of the eight 2^21-point MSMs (what all_gather + bpgpu_points_sum
+    produce) equals the single 2^24-point MSM, which runs with another window width and bucket layout.  A shard
+    prefix small enough for the CPU restatement is compared bit for bit."""
+    from bulletproofs_amd import ark_bp, sharded
+    from oracle import c_oracle as co
+    n, world = 1 << 24, 8
+    pts, sc = ark_bp.msm_bench_inputs(0, n)
+    assert co.on_curve(0, pts[:: n // 64])
+    whole = ffi.msm(0, pts, sc)
+    parts = []
+    for rank in range(world):
+        lo, hi = sharded.shard_range(n, rank, world)
+        assert hi - lo == 1 << 21
+        parts.append(ffi.msm(0, pts[lo:hi], sc[lo:hi]))
+    assert _xy(ffi.points_sum(0, np.stack(parts))) == _xy(whole) and int(whole[8]) == 0
+    k = 1 << 17
+    lo, _ = sharded.shard_range(n, 5, world)
+    want = co.msm_pippenger(0, pts[lo:lo + k], sc[lo:lo + k], threads=16)
+    got = ffi.msm(0, pts[lo:lo + k], sc[lo:lo + k])
+    assert int(got[8]) == 0 and (got[:8] == want[:8]).all()
+
+
 @pytest.mark.parametrize("pair", [True, False], ids=["pairfold", "roundfold"])
 @pytest.mark.parametrize("freeze", [0, 2, 8, 64, 1 << 15])
 def test_bp_prove_deferred_fold_equivalence(ffi, freeze, pair):
