@@ -3,7 +3,7 @@
 L=$1; shift
 for lib in "$@"; do
   echo "== $lib log2n=$L"
-  timeout -k 10 300 python tools/variant_bench.py $lib --log2n $L --no-cpu-baseline --ipa-log2n 0 --steps 20 | python -c "
+  timeout -k 10 300 python tools/variant_bench.py $lib --log2n $L --grown-points --no-cpu-baseline --ipa-log2n 0 --steps 20 | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
