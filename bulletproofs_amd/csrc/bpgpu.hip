@@ -309,44 +309,28 @@ host::HPoint<BF> horner(const uint32_t* winsums, int W, int c, int s, int nbits)
   return total;
 }
 
-// Window width.  Signed c-bit digits give 2^(c-1) buckets per window and W = ceil(256/c)
-// windows; about 32 points per bucket (c = log2 n - 4) balances bucket accumulation against the
-// bucket reduction.  The top window only holds 255 - (W-1)c significant bits; when that is a
-// handful, its few buckets each collect a large share of all points (handled by the heavy-bucket
-// path, but their bin is sorted by a single workgroup), so among the widths next to log2 n - 4
-// prefer one whose top window is well populated.
+// Window width.  Signed c-bit digits give 2^(c-1) buckets per window and W = ceil(256/c) windows.
+// Measured on MI355X (tools/wsweep.sh, tools/msm_var_probe.py, tools/ipa_rounds.py; tables in
+// profiles/r01_window_sweep.txt):
+//   * 2^16 .. 2^24: the bucket accumulation ends in a tail as long as one of its work items (64 buckets,
+//     so about one bucket's list): wider windows shorten it, until the bucket reduction (whose additions
+//     grow with the bucket count) costs more than the tail saves.  c = 15 and c = 17 also leave the top
+//     window empty for scalars below 2^254 (255 = 15 x 17 and bit 254 of a Pasta scalar is clear).
+//   * below 2^16 an MSM is a chain of latencies: short lists (about one entry per two buckets) win until
+//     the bucket reduction, twice the work in a batch of two, pushes back (single MSM of 2^15: c = 15
+//     0.38 ms, c = 13 0.45 ms; the prover's short rounds, two MSMs of 2^15 non-zero scalars: c = 13 0.65 ms,
+//     c = 15 0.76 ms per round).
+//   * outside the measured range: about 32 points per bucket (c = log2 n - 4), at most 20 bits.
 int choose_window(uint32_t n, int M) {
   if (g_ctx.window_bits) return g_ctx.window_bits;
   int lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
-  // measured optimum on MI355X for 2^16 .. 2^24 uniform scalars (tools/wsweep.sh; profiles/r01_window_sweep.txt).
-  // The bucket accumulation ends in a tail as long as one of its work items (64 buckets, so about one
-  // bucket's list): wider windows shorten it, until the bucket reduction (a fixed chain of additions
-  // whose length grows with c) costs more than the tail saves.  c = 15 and c = 17 also leave the top
-  // window holding only the carry bit (255 = 15 x 17): half a window of additions less.
-  static const int8_t best[9] = {15, 15, 16, 16, 17, 17, 17, 19, 20};
-  if (lg >= 16 && lg <= 24) return best[lg - 16];
-  // below 2^16 an MSM is a chain of latencies: short lists (about one entry per two buckets) win until the
-  // bucket reduction, twice the work in a batch of two, pushes back (profiles/r01_window_sweep.txt: single
-  // MSM of 2^15: c = 15 0.38 ms, c = 13 0.45 ms; the prover's short rounds, two MSMs of 2^15 non-zero
-  // scalars: c = 13 0.65 ms, c = 15 0.76 ms per round)
+  static const int8_t measured[9] = {15, 15, 16, 16, 17, 17, 17, 19, 20};
+  if (lg >= 16 && lg <= 24) return measured[lg - 16];
   if (lg >= 5 && lg <= 15) return M > 1 ? lg - 2 : lg;
   int c = lg - 4;
   if (c < 2) c = 2;
   if (c > 20) c = 20;
-  if (lg >= 16) {
-    int best = -1, best_d = 99;
-    for (int cand = c - 2; cand <= c + 1 && cand <= 20; cand++) {
-      int W = (256 + cand - 1) / cand;
-      int top_bits = 255 - (W - 1) * cand;
-      int d = cand > c ? cand - c : c - cand;
-      if (top_bits >= 7 && d < best_d) {
-        best = cand;
-        best_d = d;
-      }
-    }
-    if (best > 0) c = best;
-  }
   return c;
 }
 

@@ -361,18 +361,7 @@ def auto_window_bits(n: int) -> int:
         return (15, 15, 16, 16, 17, 17, 17, 19, 20)[lg - 16]   # measured optimum (choose_window's table)
     if 5 <= lg <= 15:
         return lg
-    c = min(20, max(2, lg - 4))
-    if lg >= 16:
-        best, best_d = -1, 99
-        for cand in range(c - 2, min(20, c + 1) + 1):
-            W = (256 + cand - 1) // cand
-            top_bits = 255 - (W - 1) * cand
-            d = abs(cand - c)
-            if top_bits >= 7 and d < best_d:
-                best, best_d = cand, d
-        if best > 0:
-            c = best
-    return c
+    return min(20, max(2, lg - 4))
 
 
 def last_msm_timings():
