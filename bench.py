@@ -156,12 +156,13 @@ def main():
     # PCIe-inclusive rate (host buffers in, like examples/msm_bench.rs:45-48), a few repetitions
     h2h = None
     if rank == 0:
-        reps = 3
         ffi.msm(curve, pts, sc)
-        t1 = time.perf_counter()
-        for _ in range(reps):
+        samples = []
+        for _ in range(5):
+            t1 = time.perf_counter()
             ffi.msm(curve, pts, sc)
-        h2h = (time.perf_counter() - t1) / reps
+            samples.append(time.perf_counter() - t1)
+        h2h = sorted(samples)[len(samples) // 2]  # median: the staging threads share the host with everything else
 
     out = None
     if rank == 0:
@@ -203,7 +204,7 @@ def main():
             "phases_ms": {"digits+hist": phase[0], "scan": phase[1], "scatter": phase[2], "accumulate": phase[3],
                           "reduce": phase[5], "host_tail": phase[6], "gpu_total": phase[7]},
             "host_to_host": {"ms": h2h * 1e3, "points_per_s": n / h2h,
-                             "note": "host buffers in, PCIe + Jacobian->affine conversion included (msm_bench.rs:45-48 window)"},
+                             "note": "host buffers in, PCIe + Jacobian->affine conversion included (msm_bench.rs:45-48 window); median of 5"},
         }
         if world == 1:
             out["roofline_hbm"] = scalar_kernels_leg(ffi, curve)

@@ -210,6 +210,10 @@ struct Ctx {
   Helper helper;
   PinnedBuf h_winsum;  // window sums land here (pinned: the copy is a plain DMA)
   Uploader up;
+  // the buffers of the last closed IPA session, kept for the next one (a prover makes proof after proof of
+  // one size; hipMalloc + hipFree of 460 MB cost about a millisecond per proof)
+  DevBuf ipa_pts, ipa_sc;
+  bool ipa_pool_busy = false;
 };
 
 Ctx g_ctx;
@@ -885,6 +889,7 @@ struct bpgpu_ipa {
   //          then (when short rounds defer the generator fold) 4 n0 MSM scalars and 2 n0 weights
   uint32_t* d_pts;
   uint32_t* d_sc;
+  bool pooled;  // d_pts / d_sc belong to the context's pool
   bool lr_done;
   // deferred generator folding (kernels.cuh, k_frozen_*)
   size_t freeze_cap;     // room reserved: n0 <= freeze_cap
@@ -1127,6 +1132,9 @@ void bpgpu_shutdown(void) {
                     &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip, &g_ctx.fold_plans})
     b->release();
   for (DevBuf& b : g_ctx.aux) b.release();
+  g_ctx.ipa_pts.release();
+  g_ctx.ipa_sc.release();
+  g_ctx.ipa_pool_busy = false;
   g_ctx.h_winsum.release();
   g_ctx.up.release();
   g_ctx.helper.stop();
@@ -1898,16 +1906,34 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
   s->sc_scaled = 2 * np + 2 + 6 * s->freeze_cap;
   ipa_mu_reset(s);
   const size_t sc_words = (s->sc_scaled + 2 * np) * 8;
+  s->pooled = false;
   auto cleanup = [&]() {
-    if (s->d_pts) (void)hipFree(s->d_pts);
-    if (s->d_sc) (void)hipFree(s->d_sc);
+    if (s->pooled) {
+      g_ctx.ipa_pool_busy = false;
+    } else {
+      if (s->d_pts) (void)hipFree(s->d_pts);
+      if (s->d_sc) (void)hipFree(s->d_sc);
+    }
     delete s;
   };
-  hipError_t e = hipMalloc((void**)&s->d_pts, (2 * np + 1) * 64);
-  if (e == hipSuccess) e = hipMalloc((void**)&s->d_sc, sc_words * 4);
-  if (e != hipSuccess) {
-    cleanup();
-    return fail(BPGPU_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+  if (!g_ctx.ipa_pool_busy) {
+    int prc = g_ctx.ipa_pts.ensure((2 * np + 1) * 64);
+    if (prc == 0) prc = g_ctx.ipa_sc.ensure(sc_words * 4);
+    if (prc != 0) {
+      delete s;
+      return prc;
+    }
+    s->d_pts = g_ctx.ipa_pts.as<uint32_t>();
+    s->d_sc = g_ctx.ipa_sc.as<uint32_t>();
+    s->pooled = true;
+    g_ctx.ipa_pool_busy = true;
+  } else {  // a second session open at the same time owns its buffers
+    hipError_t e = hipMalloc((void**)&s->d_pts, (2 * np + 1) * 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_sc, sc_words * 4);
+    if (e != hipSuccess) {
+      cleanup();
+      return fail(BPGPU_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
   }
   hipStream_t st = g_ctx.stream;
   int rc = 0;
@@ -2131,8 +2157,12 @@ void bpgpu_ipa_free(bpgpu_ipa* s) {
   if (!s) return;
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
-  if (s->d_pts) (void)hipFree(s->d_pts);
-  if (s->d_sc) (void)hipFree(s->d_sc);
+  if (s->pooled) {
+    g_ctx.ipa_pool_busy = false;
+  } else {
+    if (s->d_pts) (void)hipFree(s->d_pts);
+    if (s->d_sc) (void)hipFree(s->d_sc);
+  }
   delete s;
 }
 
