@@ -66,3 +66,14 @@ def test_points_sum_host_helper():
         assert H.xy_inf_to_affine(c, ffi.points_sum(c.curve_id, np.stack(rows))) == want
         assert H.xy_inf_to_affine(c, ffi.points_sum(c.curve_id, np.stack([rows[0], rows[-1]]))) is None
         assert H.xy_inf_to_affine(c, ffi.points_sum(c.curve_id, np.zeros((0, 9), np.uint64))) is None
+
+
+def test_static_archive_defines_every_declared_symbol():
+    """libbpgpu.a is what the reference's build.rs links: same object as the shared library."""
+    import subprocess
+    arc = os.path.join(ROOT, "bulletproofs_amd", "lib", "libbpgpu.a")
+    assert os.path.exists(arc), "run `make` (or __graft_entry__.build()) first"
+    out = subprocess.run(["nm", "--defined-only", "-g", arc], capture_output=True, text=True, check=True).stdout
+    defined = set(re.findall(r"\bT (bpgpu_[a-z0-9_]+)", out))
+    missing = [s for s in header_symbols() if s not in defined]
+    assert not missing, f"not defined in libbpgpu.a: {missing}"

@@ -49,3 +49,14 @@ def test_test_ipa_cli():
     assert len(lines) == 6 * 2 * 3
     sizes = [int(l.split()[-1]) for l in lines if "Proof size" in l]
     assert sizes == [2, 2, 4, 4, 6, 6, 8, 8, 10, 10, 12, 12]            # 2 log2(padded n) + 2, bp_iter.rs:187-189
+
+
+def test_static_archive_links_and_agrees():
+    """libbpgpu.a (the archive the reference's build.rs links) carries the same code object:
+    msm_bench linked statically against it prints the same point as the shared-library build."""
+    outs = []
+    for exe in ("msm_bench", "msm_bench_static"):
+        r = run(exe, 300, "-m", "pippenger", "--print-point")
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stderr.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 192
