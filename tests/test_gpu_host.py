@@ -155,3 +155,61 @@ def test_kary_step(bp, c, n, k):
         bad = got["a"].copy()
         bad[0, 0] ^= np.uint64(1)
         bp.ipa_check(cid, got["a_gens"], got["b_gens"], q, got["result"], bad, got["b"])
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_ipa_prove_verify_full_size_2_20(bp, c):
+    """BASELINE config 4 at its full size: test_ipa (src/lib.rs:110-135) at N = 2^20 over Pallas (and Vesta) with the
+    reference's own sampling recipe (src/relations/ipa.rs:28-36,90-97,110-115).  The CPU restatement needs
+    minutes per proof here, so the checks are the size-independent ones the reference itself relies on:
+    IpaRelation::check on the sample (ipa.rs:134-146), proof size 2 log2 N + 2 (bp_iter.rs:187-189),
+    verifier acceptance -- Bp::verify is ONE MSM over the ORIGINAL generators with
+    scalars_from_challenges (bp_iter.rs:130-178), a route that shares no fold with the prover -- and
+    rejection of a tampered proof; plus bit-identical proofs across the prover's schedules (pair folding
+    on / off, two freeze lengths, generators resident in HBM), which reach L, R through different MSMs.
+    The first two rounds' L, R are also compared with the oracle's single MSMs (bp_iter.rs:68-81)."""
+    from bulletproofs_amd import ffi
+    n, cid = 1 << 20, c.curve_id
+    A, B, q, a, b, seed = bp.ipa_inputs(cid, n)
+    assert co.on_curve(cid, A[:: n // 32]) and co.on_curve(cid, B[:: n // 32])
+    result = bp.commit(cid, A, B, q, a, b)
+    pf = bp.bp_prove(cid, A, B, q, a, b, seed)
+    assert len(pf["ls"]) == 20 and 2 * (1 + len(pf["ls"])) == 42
+    bp.bp_verify(cid, A, B, q, result, pf, seed)
+    for key, other in (("final_a", "final_b"), ("ls", "rs")):
+        bad = dict(pf)
+        bad[key] = pf[other]
+        with pytest.raises(bp.Panic):
+            bp.bp_verify(cid, A, B, q, result, bad, seed)
+    bad = dict(pf)
+    bad["ls"] = pf["ls"].copy()
+    bad["ls"][13] = pf["ls"][12]              # one short-round L swapped
+    with pytest.raises(bp.Panic):
+        bp.bp_verify(cid, A, B, q, result, bad, seed)
+    # round 0's L against the CPU restatement of the reference's MSM: A[n/2..] | B[..n/2] | Q with
+    # a[..n/2] | b[n/2..] | <a_lo, b_hi>  (bp_iter.rs:68-74)
+    h = n // 2
+    c_l = co.ip(cid, a[:h], b[h:])
+    l_pts = np.concatenate([A[h:], B[:h], q.reshape(1, 12)])
+    l_sc = np.concatenate([a[:h], b[h:], c_l.reshape(1, 4)])
+    want_l = co.msm_pippenger(cid, l_pts, l_sc, threads=16)
+    assert (pf["ls"][0][:8] == want_l[:8]).all()
+    # other schedules of the same prover
+    try:
+        for pair, freeze in ((False, 1 << 15), (True, 1 << 12), (False, 1 << 17)):
+            ffi.set_pair_fold(pair)
+            ffi.set_freeze_len(freeze)
+            alt = bp.bp_prove(cid, A, B, q, a, b, seed)
+            for key in ("ls", "rs", "challenges", "final_a", "final_b"):
+                assert (alt[key] == pf[key]).all(), (pair, freeze, key)
+    finally:
+        ffi.set_freeze_len(1 << 15)
+        ffi.set_pair_fold(True)
+    gens = bp.DeviceGens(cid, A, B, q)
+    try:
+        got = bp.bp_prove_cached(gens, a, b, seed)
+        for key in ("ls", "rs", "challenges", "final_a", "final_b"):
+            assert (got[key] == pf[key]).all(), key
+        bp.bp_verify_cached(gens, result, got, seed)
+    finally:
+        gens.free()
