@@ -200,6 +200,9 @@ def main():
                                          "FETCH_SIZE + WRITE_SIZE, raw (64-byte gathers); algorithmic = mixed additions x 68 B",
                          "algorithmic_bytes": adds * 68, "mixed_additions_per_launch": adds,
                          "avg_kernel_ms": phase[3],
+                         # the same kernel against the HBM roof (8 TB/s): far below it, which is why the bound is "valu"
+                         "hbm_view": {"achieved": adds * 68 / accum_s / 1e9 if accum_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                                      "frac": adds * 68 / accum_s / 8e12 if accum_s > 0 else 0.0},
                          "note": "algorithmic mads = non-zero digits (mixed additions) * 11 field-mul * 136 mad (SURVEY 8d); peak = measured v_mad_u64_u32 issue rate"},
             "phases_ms": {"digits+hist": phase[0], "scan": phase[1], "scatter": phase[2], "accumulate": phase[3],
                           "reduce": phase[5], "host_tail": phase[6], "gpu_total": phase[7]},
