@@ -204,7 +204,7 @@ def main():
                          "hbm_view": {"achieved": adds * 68 / accum_s / 1e9 if accum_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
                                       "frac": adds * 68 / accum_s / 8e12 if accum_s > 0 else 0.0},
                          "note": "algorithmic mads = non-zero digits (mixed additions) * 11 field-mul * 136 mad (SURVEY 8d); peak = measured v_mad_u64_u32 issue rate"},
-            "phases_ms": {"digits+hist": phase[0], "scan": phase[1], "scatter": phase[2], "accumulate": phase[3],
+            "phases_ms": {"digits+hist": phase[0], "scan+scatter_to_bins": phase[1], "sort_in_bins": phase[2], "accumulate": phase[3],
                           "reduce": phase[5], "host_tail": phase[6], "gpu_total": phase[7]},
             "host_to_host": {"ms": h2h * 1e3, "points_per_s": n / h2h,
                              "note": "host buffers in, PCIe + Jacobian->affine conversion included (msm_bench.rs:45-48 window); median of 5"},
