@@ -24,18 +24,17 @@ def test_msm_and_ip_from_concurrent_threads(ffi):
     for t, n in enumerate([1, 33, 257, 1000, 4096, 70000, 2, 513]):
         curve = t & 1
         pts, sc = co.msm_bench_inputs(curve, n)
-        jobs.append((curve, pts, sc, co.msm_pippenger(curve, pts, sc, threads=4)))
+        jobs.append((curve, pts, sc, co.msm_pippenger(curve, pts, sc, threads=4), np.array(co.ip(curve, sc, sc))))
 
     def work(job):
-        curve, pts, sc, want = job
+        curve, pts, sc, want, want_ip = job
         out = []
         for _ in range(3):
             got = ffi.msm(curve, pts, sc)
             # got = x, y, infinity flag; want = the restatement's normalised (X, Y, Z = 1)
             out.append(int(got[8]) == 0 and bool((got[:8] == want[:8]).all()))
-            # a scalar-only call in between: the inner product of the scalars with themselves, twice
-            a = np.array(ffi.ip(curve, sc, sc))
-            out.append(bool((a == np.array(ffi.ip(curve, sc, sc))).all()))
+            # a scalar-only call in between: the inner product of the scalars with themselves (util/mod.rs:17-23)
+            out.append(bool((np.array(ffi.ip(curve, sc, sc)).ravel() == want_ip.ravel()).all()))
         return all(out)
 
     with ThreadPoolExecutor(len(jobs)) as ex:
