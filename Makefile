@@ -40,9 +40,10 @@ $(LIBDIR)/libbpchk.so: $(CSRC)/host_check.cpp $(CSRC)/curve.cuh $(CSRC)/field.cu
 	@mkdir -p $(LIBDIR)
 	$(CXX) -O2 -std=c++17 -DBP_CHECKED -shared -fPIC -x c++ $< -o $@
 
+# x86-64-v3 (AVX2 + BMI2: every host an MI355X sits in), not -march=native: the library is built here and runs on the GPU box
 oracle/_build/libpasta_oracle.so: oracle/pasta_oracle.c
 	@mkdir -p oracle/_build
-	$(CC) -O3 -march=native -std=c11 -shared -fPIC -pthread $< -o $@
+	$(CC) -O3 -march=x86-64-v3 -std=c11 -shared -fPIC -pthread $< -o $@
 
 # the reference's two command-line drivers for this path (examples/msm_bench.rs; test_ipa of src/lib.rs:110-135)
 $(BINDIR)/%: examples/%.cpp bulletproofs_amd/host/ark_bp.hpp $(CSRC)/host_field.h $(CSRC)/pasta_consts.h include/bpgpu.h $(LIBDIR)/libbpgpu.so

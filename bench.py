@@ -4,12 +4,13 @@
 
   python bench.py --gpus N --steps K --warmup W [--log2n 20] [--curve pallas]
 
-A "step" is one MSM of 2^log2n (point, scalar) pairs per rank over operands already
-resident in HBM (the IPA-relevant case: generators are fixed public parameters), result
-returned to the host as a normalised point.  With N > 1 every rank owns a contiguous
-point range (weak scaling: 2^log2n pairs per rank); each step ends with the one real
-exchange the sharded MSM has, an all_gather of the 72-byte partial results over
-RCCL/xGMI followed by their sum (bpgpu_points_sum).  Rank 0 prints ONE JSON line.
+A "step" is one MSM over operands already resident in HBM (the IPA-relevant case: generators are
+fixed public parameters), result returned to the host as a normalised point.
+N = 1: 2^20 (point, scalar) pairs on one GPU (BASELINE config 2).
+N > 1: BASELINE config 3, STRONG scaling: ONE MSM of 2^24 pairs in total (--log2n sets the total), cut into
+contiguous point ranges [g n / N, (g+1) n / N), one per rank; every step ends with the one real exchange the
+sharded MSM has, an all_gather of the 72-byte partial results over RCCL/xGMI followed by their sum
+(bpgpu_points_sum).  Rank 0 prints ONE JSON line.
 
 Inputs are synthetic.  N = 1: the reference's own recipe (examples/msm_bench.rs:40-44, one
 ark_std::test_rng() stream: n points by G::rand, then n scalars), sampled through the host mirror
@@ -30,8 +31,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MADS_PER_FIELD_MUL = 136   # 8-limb CIOS = 2*8^2 + 8 multiply-adds
-MULS_PER_MIXED_ADD = 11    # mixed Jacobian add
+# Two ways to count the multiply-adds of a group operation:
+#  * the SURVEY 8(d) yardstick (config-independent): field mul = 8-limb CIOS = 2*8^2 + 8 = 136 mads; mixed
+#    Jacobian add = 11 field muls, doubling = 7, full add = 16;
+#  * what the compiled kernels execute (curve.cuh / field.cuh: 9 x 29-bit limbs, p = 2^254 + t): a product is 81
+#    mads (a square 45), a Montgomery reduction 45; XYZZ mixed add madd-2008-s = 6 products + 2 squares + one
+#    two-product accumulation (Y3) with 9 reductions = 1143 mads; doubling dbl-2008-s-1 = 6 products + 3 squares
+#    (Y3 two products, one reduction) with 8 reductions = 1062 mads.
+# `frac` uses the yardstick (comparable across implementations); `frac_executed` uses the second count.
+MADS_PER_FIELD_MUL = 136
+MULS_PER_MIXED_ADD = 11
+MULS_PER_DOUBLE = 7
+EXEC_MADS_MIXED_ADD = 6 * 81 + 2 * 45 + 2 * 81 + 9 * 45   # 1143
+EXEC_MADS_DOUBLE = 5 * 81 + 3 * 45 + 2 * 81 + 8 * 45      # 1062
+EXEC_MADS_FIELD_MUL = 81 + 45                              # 126
 
 
 def synth_points(ffi, curve, n, seed):
@@ -72,12 +85,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2n", type=int, default=20, help="log2 of the points per rank")
+    ap.add_argument("--log2n", type=int, default=None,
+                    help="log2 of the MSM size: points on the one GPU (default 20), or TOTAL points over all ranks when "
+                         "--gpus > 1 (default 24: config 3)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: --log2n is per rank (weak scaling) instead of the total")
     ap.add_argument("--curve", default="pallas", choices=["pallas", "vesta"])
     ap.add_argument("--window", type=int, default=0, help="override the MSM window width (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=20, help="log2 of the CPU-baseline sample size")
     ap.add_argument("--ipa-log2n", type=int, default=20, help="log2 N of the secondary IPA-prove measurement (0 = skip)")
+    ap.add_argument("--ipa-cpu-log2n", type=int, default=16,
+                    help="log2 N of the CPU baseline of Bp::prove (Oracle B on the host cores; 2^16 takes seconds, 2^20 a minute)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --one-device rehearses N > 1 ranks on a single GPU")
     ap.add_argument("--grown-points", action="store_true",
@@ -108,7 +126,17 @@ def main():
     if args.window:
         ffi.set_window_bits(args.window)
     curve = 0 if args.curve == "pallas" else 1
-    n = 1 << args.log2n
+    from bulletproofs_amd import sharded
+    if args.log2n is None:
+        args.log2n = 20 if world == 1 else 24
+    strong = world > 1 and not args.weak
+    if strong:
+        total = 1 << args.log2n
+        lo, hi = sharded.shard_range(total, rank, world)
+        n = hi - lo
+    else:
+        n = 1 << args.log2n
+        total = world * n
 
     if world == 1 and not args.grown_points:
         # the reference's own recipe (examples/msm_bench.rs:40-44): one test_rng() stream, n points by G::rand
@@ -123,7 +151,6 @@ def main():
     d_pts = ffi.points_to_device(curve, pts, fmt=0)
     d_sc = ffi.scalars_to_device(sc)
 
-    from bulletproofs_amd import sharded
     dev = torch.device("cuda", dev_index) if args.backend == "nccl" else None
 
     def step():
@@ -147,11 +174,18 @@ def main():
         entries += ffi.last_msm_entries()
     sync()
     dt = time.perf_counter() - t0
+    phase /= max(1, args.steps)
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    phase /= max(1, args.steps)
+        # every rank's accumulate-phase time and addition count, for the per-GPU roofline fractions
+        mine = torch.tensor([phase[3], entries / max(1, args.steps), float(n), phase[7]], dtype=torch.float64,
+                            device="cuda" if args.backend == "nccl" else "cpu")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(v) for v in r.cpu()] for r in allr]
 
     # PCIe-inclusive rate (host buffers in, like examples/msm_bench.rs:45-48), a few repetitions
     h2h = None
@@ -170,6 +204,7 @@ def main():
         c_bits = args.window or ffi.auto_window_bits(n)
         W = (256 + c_bits - 1) // c_bits
         accum_s = phase[3] * 1e-3
+        yard = MULS_PER_MIXED_ADD * MADS_PER_FIELD_MUL
         # additions the kernel actually performed: one per non-zero digit (measured by the library).  With
         # c = 17 the 16th window is empty for Pasta scalars (15 x 17 = 255 bits, bit 254 is clear below r), so
         # this is 15 n, not windows x n
@@ -178,41 +213,51 @@ def main():
         achieved = algo_mads / accum_s if accum_s > 0 else 0.0
         out = {
             "metric": "MSM points/sec (Pallas, variable-base)" if curve == 0 else "MSM points/sec (Vesta, variable-base)",
-            "value": world * n * args.steps / dt,
+            "value": total * args.steps / dt,
             "unit": "points/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u32 limbs (255-bit Montgomery, 9x29-bit, int64 accumulate)",
             "data": "synthetic",
-            "config": {"workload": f"2^{args.log2n}-point {args.curve} MSM per GPU, operands resident in HBM",
-                       "inputs": recipe, "points_per_gpu": n, "total_points": world * n, "window_bits": c_bits, "windows": W,
+            "config": {"workload": (f"2^{args.log2n}-point {args.curve} MSM sharded across {world} GPUs (contiguous point ranges), "
+                                    "operands resident in HBM" if strong else
+                                    f"2^{args.log2n}-point {args.curve} MSM per GPU, operands resident in HBM"),
+                       "inputs": recipe, "points_per_gpu": n, "total_points": total, "window_bits": c_bits, "windows": W,
                        "parallelism": f"point-range shards x{world}, all_gather of 72 B partials" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "kernel": "k_accum (bucket accumulation, mixed XYZZ adds)",
                          "achieved": achieved / 1e12, "peak": mad_peak / 1e12, "unit": "Tmad/s",
                          "frac": achieved / mad_peak if mad_peak else None,
-                         "traffic": pmc_traffic("k_accum", False) if (args.log2n == 20 and curve == 0 and not args.window) else None,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 PMC of this command (profiles/r01_pmc_summary.csv): "
-                                         "FETCH_SIZE + WRITE_SIZE, raw (64-byte gathers); algorithmic = mixed additions x 68 B",
+                         "frac_executed": (adds * EXEC_MADS_MIXED_ADD / accum_s / mad_peak) if (mad_peak and accum_s > 0) else None,
+                         "mads_per_mixed_add": {"yardstick": yard, "executed": EXEC_MADS_MIXED_ADD},
+                         "traffic": pmc_traffic("k_accum", False) if (world == 1 and args.log2n == 20 and curve == 0 and not args.window) else None,
+                         "traffic_note": f"HBM bytes per launch from the committed rocprofv3 PMC passes of this command ({os.path.basename(PMC_SUMMARY)}, "
+                                         "not measured in this run): FETCH_SIZE + WRITE_SIZE, raw (64-byte gathers); algorithmic = mixed additions x 68 B",
                          "algorithmic_bytes": adds * 68, "mixed_additions_per_launch": adds,
                          "avg_kernel_ms": phase[3],
                          # the same kernel against the HBM roof (8 TB/s): far below it, which is why the bound is "valu"
                          "hbm_view": {"achieved": adds * 68 / accum_s / 1e9 if accum_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
                                       "frac": adds * 68 / accum_s / 8e12 if accum_s > 0 else 0.0},
-                         "note": "algorithmic mads = non-zero digits (mixed additions) * 11 field-mul * 136 mad (SURVEY 8d); peak = measured v_mad_u64_u32 issue rate"},
+                         "note": "frac: algorithmic mads = non-zero digits (mixed additions) * 11 field-mul * 136 mad (SURVEY 8d yardstick); "
+                                 "frac_executed: the 1143 multiply-adds the compiled XYZZ mixed add issues per addition; peak = measured v_mad_u64_u32 issue rate"},
             "phases_ms": {"digits+hist": phase[0], "scan+scatter_to_bins": phase[1], "sort_in_bins": phase[2], "accumulate": phase[3],
                           "reduce": phase[5], "host_tail": phase[6], "gpu_total": phase[7]},
             "host_to_host": {"ms": h2h * 1e3, "points_per_s": n / h2h,
                              "note": "host buffers in, PCIe + Jacobian->affine conversion included (msm_bench.rs:45-48 window); median of 5"},
         }
+        if per_rank is not None:
+            out["per_gpu"] = [{"rank": r, "points": int(v[2]), "k_accum_ms": v[0], "gpu_total_ms": v[3],
+                               "k_accum_frac": (v[1] * yard / (v[0] * 1e-3) / mad_peak) if (v[0] > 0 and mad_peak) else None}
+                              for r, v in enumerate(per_rank)]
         if world == 1:
-            out["roofline_hbm"] = scalar_kernels_leg(ffi, curve)
+            out["roofline_hbm"] = scalar_kernels_leg(ffi, curve, mad_peak)
         if world == 1 and args.ipa_log2n:
-            out["ipa_prove"] = ipa_prove_leg(ffi, curve, args.ipa_log2n)
+            out["roofline_fold"] = fold_kernels_leg(ffi, curve, args.ipa_log2n, mad_peak)
+            out["ipa_prove"] = ipa_prove_leg(ffi, curve, args.ipa_log2n, 0 if args.no_cpu_baseline else args.ipa_cpu_log2n)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ffi, curve, pts, sc, min(args.cpu_log2n, args.log2n))
         print(json.dumps(out), flush=True)
@@ -221,7 +266,7 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
 
 
 def pmc_traffic(kernel, streaming):
@@ -243,11 +288,12 @@ def pmc_traffic(kernel, streaming):
         return None
 
 
-def scalar_kernels_leg(ffi, curve, log2n=24):
-    """HBM roofline of the two streaming kernels of the fold (north-star: "HBM GB/s for scalar folding"):
-    k_fold_scalars (a' = x a_lo + x^-1 a_hi, bp_iter.rs:88-95: 64 B read + 32 B written per output) and
-    k_ip_partial (<a, b>, util/mod.rs:17-23: 64 B read per term), on vectors far larger than the 256 MiB
-    Infinity Cache, timed with HIP events on the library's stream."""
+def scalar_kernels_leg(ffi, curve, mad_peak, log2n=24):
+    """Both ceilings of the two streaming kernels of the fold (north-star: "HBM GB/s for scalar folding"; SURVEY 8d:
+    "report both ceilings and which one binds"): k_fold_scalars (a' = x a_lo + x^-1 a_hi, bp_iter.rs:88-95: 64 B read +
+    32 B written and two field multiplications per output) and k_ip_partial (<a, b>, util/mod.rs:17-23: 64 B read and one
+    multiplication per term), on vectors far larger than the 256 MiB Infinity Cache, timed with HIP events on the
+    library's stream."""
     n = 1 << log2n
     v = synth_scalars(2 * n, 91)
     d_v = ffi.scalars_to_device(v)
@@ -267,16 +313,80 @@ def scalar_kernels_leg(ffi, curve, log2n=24):
     peak = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md); about 6300 GB/s is achievable
     fold_gbs = n * 96 / (best_fold * 1e-3) / 1e9
     ip_gbs = n * 64 / (best_ip * 1e-3) / 1e9
+
+    def valu(mults, ms):
+        # integer ceiling of the same launch: yardstick (136 mads per multiplication) and executed (126) counts
+        if not mad_peak:
+            return None
+        return {"achieved_Tmad_s": n * mults * MADS_PER_FIELD_MUL / (ms * 1e-3) / 1e12, "peak_Tmad_s": mad_peak / 1e12,
+                "frac": n * mults * MADS_PER_FIELD_MUL / (ms * 1e-3) / mad_peak,
+                "frac_executed": n * mults * EXEC_MADS_FIELD_MUL / (ms * 1e-3) / mad_peak}
+    fold_valu, ip_valu = valu(2, best_fold), valu(1, best_ip)
     return {"bound": "hbm", "kernel": "k_fold_scalars", "achieved": fold_gbs, "peak": peak, "unit": "GB/s",
             "frac": fold_gbs / peak, "traffic": pmc_traffic("k_fold_scalars", True) if (log2n == 24 and curve == 0) else None,
-            "traffic_note": "bytes per launch, rocprofv3 PMC (profiles/r01_pmc_summary.csv): 2 x FETCH_SIZE + WRITE_SIZE; algorithmic = outputs x 96 B",
+            "traffic_note": f"bytes per launch from the committed rocprofv3 PMC passes ({os.path.basename(PMC_SUMMARY)}, not measured in this "
+                            "run): 2 x FETCH_SIZE + WRITE_SIZE; algorithmic = outputs x 96 B",
             "avg_kernel_ms": best_fold,
             "outputs": n, "algorithmic_bytes_per_output": 96,
+            "valu_ceiling": fold_valu,
+            "binds": "both: the kernel issues ~580 VALU instructions per output (unpack, two multiplications, canonical "
+                     "reduction, pack), so VALU issue time is within 15 % of the HBM time (profiles/, PMC SQ_INSTS_VALU); HBM is "
+                     "the higher of the two fractions",
             "k_ip": {"achieved": ip_gbs, "frac": ip_gbs / peak, "kernel_ms": best_ip, "terms": n,
-                     "algorithmic_bytes_per_term": 64}}
+                     "algorithmic_bytes_per_term": 64, "valu_ceiling": ip_valu, "binds": "hbm"}}
 
 
-def ipa_prove_leg(ffi, curve, log2n):
+def fold_kernels_leg(ffi, curve, log2n, mad_peak):
+    """Integer roofline of the generator-fold kernels (a6, bp_iter.rs:97-104) as the prover launches them at N = 2^log2n:
+    k_fold_joint4 (two rounds at once, 2 x N/4 outputs) and k_fold_monic (one round, 2 x N/2 outputs).  Group operations
+    are the ones the launch executed (bpgpu_last_fold_ops: doublings = recoded length, mixed additions = non-zero digits),
+    priced by the SURVEY yardstick (7 / 11 field muls x 136 mads) and by the executed count; kernel time from HIP events."""
+    n = 1 << log2n
+    if n < 8:
+        return None
+    r_mod = [0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001,
+             0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001][curve]
+    R = 1 << 256
+
+    def ark(v):
+        return np.frombuffer((v * R % r_mod).to_bytes(32, "little"), dtype=np.uint64)
+    pts = synth_points(ffi, curve, 2 * n + 1, seed=77)
+    a, b = synth_scalars(n, 78), synth_scalars(n, 79)
+    d_a, d_b, d_q = (ffi.points_to_device(curve, pts[:n]), ffi.points_to_device(curve, pts[n:2 * n]),
+                     ffi.points_to_device(curve, pts[2 * n:]))
+    out = {}
+    rng = np.random.default_rng(5)
+    for name, pair in (("k_fold_joint4", True), ("k_fold_monic", False)):
+        ffi.set_pair_fold(pair)
+        best, ops = 1e9, None
+        for _ in range(2):
+            sess = ffi.IpaSession.from_device(curve, d_a, d_b, d_q, a, b)
+            for _round in range(2 if pair else 1):
+                sess.round_lr()
+                x = int.from_bytes(rng.bytes(31), "little") | 1
+                sess.round_fold(ark(x), ark(pow(x, -1, r_mod)))
+            ms, ops = ffi.last_op_ms(), ffi.last_fold_ops()
+            sess.free()
+            best = min(best, ms)
+        outputs, dbls, adds, kind = ops
+        assert kind == (2 if pair else 1), "unexpected fold kernel"
+        yard = (dbls * MULS_PER_DOUBLE + adds * MULS_PER_MIXED_ADD) * MADS_PER_FIELD_MUL
+        execd = dbls * EXEC_MADS_DOUBLE + adds * EXEC_MADS_MIXED_ADD
+        out[name] = {"bound": "valu", "outputs": outputs, "doublings_per_output": dbls / outputs,
+                     "mixed_additions_per_output": adds / outputs, "kernel_ms": best,
+                     "achieved": yard / (best * 1e-3) / 1e12, "peak": mad_peak / 1e12, "unit": "Tmad/s",
+                     "frac": yard / (best * 1e-3) / mad_peak if mad_peak else None,
+                     "frac_executed": execd / (best * 1e-3) / mad_peak if mad_peak else None}
+    ffi.set_pair_fold(True)
+    for buf in (d_a, d_b, d_q):
+        buf.free()
+    out["note"] = ("group operations executed by the launch (doublings = length of the recoded shared multipliers, mixed additions = "
+                   "their non-zero digits + 1) x SURVEY 8(d) costs (7 / 11 field muls x 136 mads); frac_executed uses the compiled "
+                   "counts (1062 / 1143 mads); the batched inversion back to affine (about 9 multiplications per output) is not counted")
+    return out
+
+
+def ipa_prove_leg(ffi, curve, log2n, cpu_log2n=0):
     """Secondary metric of BASELINE.json: classic Bulletproofs IPA prove (Bp::prove, reference
     src/proofs/bp_iter.rs:49-128) at N = 2^log2n through the C++ host side; the timed window is the
     reference's own (around i.prove, src/lib.rs:119-121): host vectors in, proof out, Fiat-Shamir
@@ -301,12 +411,47 @@ def ipa_prove_leg(ffi, curve, log2n):
     pc_ms = min(ark_bp.bp_prove_cached(gens, a, b, seed)["prove_ms"] for _ in range(3))
     vc_ms = min(ark_bp.bp_verify_cached(gens, result, pf, seed) for _ in range(3))
     gens.free()
+    cpu = ipa_cpu_baseline(ffi, curve, pts, n, a, b, seed, min(cpu_log2n, log2n)) if cpu_log2n else None
     return {"n": n, "prove_ms": best, "runs_ms": ms, "rounds": len(pf["ls"]), "proof_elements": 2 * (1 + len(pf["ls"])),
+            "cpu_baseline": cpu,
             "reference_published_s": ref_s, "speedup_vs_reference_published": (ref_s * 1e3 / best) if ref_s else None,
             "verify_ms": v_ms, "reference_published_verify_s": ref_v,
             "prove_ms_generators_resident": pc_ms, "verify_ms_generators_resident": vc_ms,
             "note": "host-resident inputs, upload + 2*log2(N) MSMs + folds + host Fiat-Shamir; verify = transcript replay + "
                     "one device MSM of 2N+1+2log2(N) terms; reference numbers are from unknown CPU hardware"}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def ipa_cpu_baseline(ffi, curve, pts, n, a, b, seed, log2s):
+    """Oracle B's Bp::prove (restatement of src/proofs/bp_iter.rs:49-128; window of src/lib.rs:119-121) on the host
+    cores, on the first 2^log2s generators / witness elements of the bench inputs, next to the GPU prove of the SAME
+    sample, whose proof is checked against it element by element."""
+    from bulletproofs_amd import ark_bp
+    from oracle import c_oracle as co
+    ns = 1 << log2s
+    threads = min(16, os.cpu_count() or 1)
+    co.load(threads)
+    A, B, q = pts[:ns], pts[n:n + ns], pts[2 * n:]
+    t0 = time.perf_counter()
+    ls, rs, ch, fa, fb = co.bp_prove(curve, A, B, q, a[:ns], b[:ns], seed, threads=threads)
+    cpu_s = time.perf_counter() - t0
+    g = min((ark_bp.bp_prove(curve, A, B, q, a[:ns], b[:ns], seed) for _ in range(2)), key=lambda p: p["prove_ms"])
+    same = (len(g["ls"]) == len(ls) and all((g["ls"][k][:8] == ls[k][:8]).all() and (g["rs"][k][:8] == rs[k][:8]).all()
+                                            for k in range(len(ls)))
+            and (g["final_a"] == fa).all() and (g["final_b"] == fb).all())
+    return {"value": cpu_s * 1e3, "unit": "ms", "n": ns, "cores": threads, "cpu": cpu_model(), "kind": "port",
+            "sample": f"Bp::prove over the first 2^{log2s} generators / witness elements of the bench inputs",
+            "gpu_prove_ms_same_sample": g["prove_ms"], "speedup_same_sample": cpu_s * 1e3 / g["prove_ms"],
+            "gpu_proof_matches_cpu": bool(same)}
 
 
 def cpu_baseline(ffi, curve, pts, sc, log2s):
@@ -322,12 +467,14 @@ def cpu_baseline(ffi, curve, pts, sc, log2s):
     dt = time.perf_counter() - t0
     got = ffi.msm(curve, pts[:ns], sc[:ns])
     ok = (int(got[8]) == 0 and bool((got[:8] == want[:8]).all())) or (int(got[8]) == 1 and not want[8:].any())
+    # one host thread, on a 2^16 sample (the reference's config 1 size) so that the bench stays short
+    n1 = min(ns, 1 << 16)
     t1 = time.perf_counter()
-    co.msm_pippenger(curve, pts[:ns], sc[:ns], threads=1) if log2s <= 15 else None
-    dt1 = time.perf_counter() - t1 if log2s <= 15 else None
-    return {"value": ns / dt, "unit": "points/s", "cores": threads, "kind": "port",
+    co.msm_pippenger(curve, pts[:n1], sc[:n1], threads=1)
+    dt1 = time.perf_counter() - t1
+    return {"value": ns / dt, "unit": "points/s", "cores": threads, "cpu": cpu_model(), "kind": "port",
             "sample": f"first 2^{log2s} pairs of the bench inputs, window c={co.load(threads).po_pippenger_window(ctypes.c_size_t(ns))}, {dt:.2f} s",
-            "single_thread_points_per_s": (ns / dt1) if dt1 else None,
+            "single_thread_points_per_s": n1 / dt1, "single_thread_sample": f"first {n1} pairs, {dt1:.2f} s",
             "gpu_matches_cpu_on_sample": bool(ok)}
 
 

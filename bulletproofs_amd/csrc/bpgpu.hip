@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <atomic>
+#include <memory>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -145,9 +147,65 @@ class Helper {
   bool busy_ = false, quit_ = false;
 };
 
+// N persistent worker threads; run(f) executes f(w) on every worker w and returns when all are done.
+// (The staging copies of a large upload and the per-GPU legs of a sharded MSM: a fresh std::thread per
+// call costs tens of microseconds each and a new HIP thread context.)
+class Pool {
+ public:
+  ~Pool() { stop(); }
+  void start(int n) {
+    if (!th_.empty()) return;
+    quit_ = false;
+    n_ = n;
+    for (int w = 0; w < n; w++)
+      th_.emplace_back([this, w] {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+          cv_.wait(lk, [&] { return quit_ || gen_ != seen; });
+          if (quit_) return;
+          seen = gen_;
+          lk.unlock();
+          job_(w);
+          lk.lock();
+          if (--pending_ == 0) done_.notify_all();
+        }
+      });
+  }
+  void stop() {
+    if (th_.empty()) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+    th_.clear();
+  }
+  int size() const { return n_; }
+  // one run at a time (callers hold the owning context's mutex, or the registry's for the shard pool)
+  void run(const std::function<void(int)>& f) {
+    std::unique_lock<std::mutex> lk(mu_);
+    job_ = f;
+    pending_ = n_;
+    gen_++;
+    cv_.notify_all();
+    done_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::function<void(int)> job_;
+  uint64_t gen_ = 0;
+  int pending_ = 0, n_ = 0;
+  bool quit_ = false;
+};
+
 // Large host-to-device copies.  hipMemcpyAsync from pageable memory moves 29 GB/s on the MI355X box, from
-// pinned memory 57 GB/s (tools/h2d_probe.py), and one host core copies 32 GB/s: three worker threads stage
-// 4 MiB chunks into pinned buffers, each chunk's DMA following on the worker's own stream.
+// pinned memory 57 GB/s (tools/h2d_probe.py), and one host core copies 32 GB/s: three persistent worker
+// threads stage 4 MiB chunks into pinned buffers, each chunk's DMA following on the worker's own stream.
 struct Uploader {
   static constexpr int T = 3, SLOTS = 2;
   static constexpr size_t CH = 4u << 20, MIN_BYTES = 8u << 20;
@@ -156,6 +214,7 @@ struct Uploader {
   hipStream_t ws[T] = {};
   hipEvent_t ev[T][SLOTS] = {};
   hipEvent_t fence = nullptr, done[T] = {};
+  Pool pool;
   hipError_t init() {
     if (ready) return hipSuccess;
     hipError_t e = hipEventCreateWithFlags(&fence, hipEventDisableTiming);
@@ -167,10 +226,12 @@ struct Uploader {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[w][k], hipEventDisableTiming);
       }
     }
+    if (e == hipSuccess) pool.start(T);
     ready = e == hipSuccess;
     return e;
   }
   void release() {
+    pool.stop();
     for (int w = 0; w < T; w++) {
       if (ws[w]) (void)hipStreamSynchronize(ws[w]);
       for (int k = 0; k < SLOTS; k++) {
@@ -190,22 +251,26 @@ struct Uploader {
   }
 };
 
+// One context = one HIP device, one stream, one grow-only workspace, one mutex.  The single-device entry
+// points use the calling thread's current context: the primary one (bpgpu_init) unless the thread is a
+// shard worker or is inside a call on an IPA session, which carries its own context.  Several contexts may
+// sit on one physical GPU (bpgpu_sharded_init with repeated device numbers: rehearsal of the multi-GPU path).
 struct Ctx {
+  std::mutex mu;
   bool ready = false;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
   hipEvent_t op_ev[2] = {};  // around the last ip / fold launch (bpgpu_last_op_ms)
-  int window_bits = 0;
-  size_t freeze_len = 1u << 15;  // vectors this short defer the generator fold (0 = never)
-  bool pair_fold = true;         // long rounds fold their generators two rounds at a time (k_fold_joint4)
   int num_cus = 256;
   float msm_ms[8] = {};
   uint64_t msm_entries = 0;  // non-zero digits of the last MSM batch = bucket-accumulation additions
+  uint64_t fold_ops[4] = {};  // last generator-fold launch: outputs, doublings, mixed additions (all lanes), kernel kind
+  int open_sessions = 0;     // IPA sessions that still point at this context
   // MSM workspace (grow-only)
   DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy, bcount, redtmp;
   // staging for host-buffer entry points
-  DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip, fold_plans;
+  DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
   DevBuf aux[6];  // sparse products (row pointers, indices, permutation, values, vector, result), point sampling
   Helper helper;
   PinnedBuf h_winsum;  // window sums land here (pinned: the copy is a plain DMA)
@@ -216,14 +281,39 @@ struct Ctx {
   bool ipa_pool_busy = false;
 };
 
-Ctx g_ctx;
-std::mutex g_mu;
+Ctx g_primary;                              // bpgpu_init
+std::vector<std::unique_ptr<Ctx>> g_shards;  // bpgpu_sharded_init, one per (logical) GPU of the sharded MSM
+Pool g_shard_pool;                          // one persistent host thread per shard context
+std::mutex g_reg_mu;                        // shard registry and sharded calls (one sharded MSM at a time)
+thread_local Ctx* tl_ctx = nullptr;
+inline Ctx& cx() { return tl_ctx ? *tl_ctx : g_primary; }
+
+// Tuning knobs are process-wide (documented so in bpgpu.h): results never depend on them.
+std::atomic<int> g_window_bits{0};
+std::atomic<size_t> g_freeze_len{1u << 15};  // vectors this short defer the generator fold (0 = never)
+std::atomic<bool> g_pair_fold{true};         // long rounds fold their generators two rounds at a time (k_fold_joint4)
+
+// Serialises the calls on the current context; with an explicit context (an IPA session's) that context is
+// also made current for the scope.
+struct CtxLock {
+  Ctx* prev;
+  std::unique_lock<std::mutex> lk;
+  CtxLock() : prev(tl_ctx), lk(cx().mu) {}
+  explicit CtxLock(Ctx* c) : prev(tl_ctx) {
+    tl_ctx = c;
+    lk = std::unique_lock<std::mutex>(c->mu);
+  }
+  ~CtxLock() {
+    lk.unlock();
+    tl_ctx = prev;
+  }
+};
 
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 int check_ready() {
-  if (!g_ctx.ready) return fail(BPGPU_E_NOINIT, "bpgpu_init has not been called");
-  HIP_TRY(hipSetDevice(g_ctx.device));  // the current device is per host thread
+  if (!cx().ready) return fail(BPGPU_E_NOINIT, "bpgpu_init has not been called");
+  HIP_TRY(hipSetDevice(cx().device));  // the current device is per host thread
   return 0;
 }
 int check_curve(int curve) {
@@ -234,33 +324,28 @@ int check_curve(int curve) {
 // hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) for a pageable src: ordered after the work
 // already on st and before the work that follows on it.  Returns once src has been read.
 hipError_t upload_async(void* dst, const void* src, size_t bytes, hipStream_t st) {
-  Uploader& U = g_ctx.up;
+  Uploader& U = cx().up;
   if (bytes < Uploader::MIN_BYTES) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
   hipError_t e = U.init();
   if (e != hipSuccess) return e;
   if ((e = hipEventRecord(U.fence, st)) != hipSuccess) return e;
   const size_t nch = (bytes + Uploader::CH - 1) / Uploader::CH;
-  const int device = g_ctx.device;
+  const int device = cx().device;
   hipError_t err[Uploader::T];
-  std::thread th[Uploader::T];
-  for (int w = 0; w < Uploader::T; w++) {
-    err[w] = hipSuccess;
-    th[w] = std::thread([&, w] {
-      hipError_t r = hipSetDevice(device);
-      if (r == hipSuccess) r = hipStreamWaitEvent(U.ws[w], U.fence, 0);
-      for (size_t k = (size_t)w; k < nch && r == hipSuccess; k += Uploader::T) {
-        const int slot = (int)((k / Uploader::T) % Uploader::SLOTS);
-        const size_t off = k * Uploader::CH, len = bytes - off < Uploader::CH ? bytes - off : Uploader::CH;
-        if ((r = hipEventSynchronize(U.ev[w][slot])) != hipSuccess) break;  // the slot's previous DMA has drained
-        memcpy(U.buf[w][slot], (const char*)src + off, len);
-        if ((r = hipMemcpyAsync((char*)dst + off, U.buf[w][slot], len, hipMemcpyHostToDevice, U.ws[w])) != hipSuccess) break;
-        r = hipEventRecord(U.ev[w][slot], U.ws[w]);
-      }
-      if (r == hipSuccess) r = hipEventRecord(U.done[w], U.ws[w]);
-      err[w] = r;
-    });
-  }
-  for (int w = 0; w < Uploader::T; w++) th[w].join();
+  U.pool.run([&](int w) {
+    hipError_t r = hipSetDevice(device);
+    if (r == hipSuccess) r = hipStreamWaitEvent(U.ws[w], U.fence, 0);
+    for (size_t k = (size_t)w; k < nch && r == hipSuccess; k += Uploader::T) {
+      const int slot = (int)((k / Uploader::T) % Uploader::SLOTS);
+      const size_t off = k * Uploader::CH, len = bytes - off < Uploader::CH ? bytes - off : Uploader::CH;
+      if ((r = hipEventSynchronize(U.ev[w][slot])) != hipSuccess) break;  // the slot's previous DMA has drained
+      memcpy(U.buf[w][slot], (const char*)src + off, len);
+      if ((r = hipMemcpyAsync((char*)dst + off, U.buf[w][slot], len, hipMemcpyHostToDevice, U.ws[w])) != hipSuccess) break;
+      r = hipEventRecord(U.ev[w][slot], U.ws[w]);
+    }
+    if (r == hipSuccess) r = hipEventRecord(U.done[w], U.ws[w]);
+    err[w] = r;
+  });
   for (int w = 0; w < Uploader::T; w++) {
     if (err[w] != hipSuccess) return err[w];
     if ((e = hipStreamWaitEvent(st, U.done[w], 0)) != hipSuccess) return e;
@@ -326,7 +411,7 @@ host::HPoint<BF> horner(const uint32_t* winsums, int W, int c, int s, int nbits)
 //     c = 15 0.76 ms per round).
 //   * outside the measured range: about 32 points per bucket (c = log2 n - 4), at most 20 bits.
 int choose_window(uint32_t n, int M) {
-  if (g_ctx.window_bits) return g_ctx.window_bits;
+  if (const int forced = g_window_bits.load()) return forced;
   int lg = 0;
   while ((1ull << (lg + 1)) <= n) lg++;
   static const int8_t measured[9] = {15, 15, 16, 16, 17, 17, 17, 19, 20};
@@ -343,7 +428,7 @@ int choose_window(uint32_t n, int M) {
 template <int CURVE>
 int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, uint64_t (*out)[9]) {
   constexpr int BF = CURVE, SF = 1 - CURVE;
-  Ctx& C = g_ctx;
+  Ctx& C = cx();
   for (int m = 0; m < plan.M; m++) {
     memset(out[m], 0, 72);
     out[m][8] = 1;
@@ -353,6 +438,13 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const int W = (256 + c - 1) / c;
   plan.c = c;
   plan.W = W;
+  // the sort keeps entry positions, bin and bucket offsets in 32 bits, and an entry is index | sign << 31
+  if ((uint64_t)plan.M * plan.n * (uint64_t)W >= (1ull << 32))
+    return fail(BPGPU_E_ARG, "MSM of %d x %u points in %d windows has 2^32 or more (point, window) pairs", plan.M, plan.n, W);
+  for (int m = 0; m < plan.M; m++)
+    for (int g = 0; g < 3; g++)
+      if ((uint64_t)plan.seg[m][g].pt_off + plan.seg[m][g].count > (1ull << 31))
+        return fail(BPGPU_E_ARG, "point index beyond 2^31");
   const uint32_t B = 1u << (c - 1);
   const uint32_t NB = (uint32_t)plan.M * W * B;
   const uint64_t slots = (uint64_t)plan.M * plan.n;
@@ -517,9 +609,9 @@ MsmPlan single_plan(uint32_t n) {
 int points_in(int curve, const uint32_t* d_in, uint32_t* d_out, size_t n, int fmt) {
   if (n == 0) return 0;
   if (curve == BPGPU_PALLAS)
-    k_points_in<0><<<cdiv(n, 64), 64, 0, g_ctx.stream>>>(d_in, d_out, (uint32_t)n, fmt);
+    k_points_in<0><<<cdiv(n, 64), 64, 0, cx().stream>>>(d_in, d_out, (uint32_t)n, fmt);
   else
-    k_points_in<1><<<cdiv(n, 64), 64, 0, g_ctx.stream>>>(d_in, d_out, (uint32_t)n, fmt);
+    k_points_in<1><<<cdiv(n, 64), 64, 0, cx().stream>>>(d_in, d_out, (uint32_t)n, fmt);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -527,32 +619,40 @@ int points_in(int curve, const uint32_t* d_in, uint32_t* d_out, size_t n, int fm
 int points_out(int curve, const uint32_t* d_in, uint32_t* d_out, size_t n) {
   if (n == 0) return 0;
   if (curve == BPGPU_PALLAS)
-    k_points_out<0><<<cdiv(n, 256), 256, 0, g_ctx.stream>>>(d_in, d_out, (uint32_t)n);
+    k_points_out<0><<<cdiv(n, 256), 256, 0, cx().stream>>>(d_in, d_out, (uint32_t)n);
   else
-    k_points_out<1><<<cdiv(n, 256), 256, 0, g_ctx.stream>>>(d_in, d_out, (uint32_t)n);
+    k_points_out<1><<<cdiv(n, 256), 256, 0, cx().stream>>>(d_in, d_out, (uint32_t)n);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
-// <a, b> for up to two pairs at once; results (ark form) land in d_out0 / d_out1.
-int ip_launch(int curve, const uint32_t* d_sc, IpPair p0, IpPair p1, int npairs, uint32_t n, uint32_t* d_out0,
-              uint32_t* d_out1) {
-  Ctx& C = g_ctx;
+// <a, b> for up to two pairs at once (a's offsets are relative to d_a, b's to d_b); results (ark form) land in
+// d_out0 / d_out1.  d_partial: room for 2 * ip_blocks(n) block sums of 32 bytes.
+uint32_t ip_blocks(uint32_t n) {
   uint32_t nblk = n == 0 ? 1 : cdiv(n, 256 * 8);
-  if (nblk > 1024) nblk = 1024;
-  TRY(C.st_ip.ensure((size_t)2 * nblk * 32));
+  return nblk > 1024 ? 1024 : nblk;
+}
+int ip_launch_with(int curve, const uint32_t* d_a, const uint32_t* d_b, IpPair p0, IpPair p1, int npairs, uint32_t n,
+                   uint32_t* d_partial, uint32_t* d_out0, uint32_t* d_out1) {
+  Ctx& C = cx();
+  const uint32_t nblk = ip_blocks(n);
   dim3 grid(nblk, npairs);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
   if (curve == BPGPU_PALLAS) {
-    k_ip_partial<1><<<grid, 256, 0, C.stream>>>(d_sc, p0, p1, n, C.st_ip.as<uint32_t>());
-    k_ip_final<1><<<npairs, 256, 0, C.stream>>>(C.st_ip.as<uint32_t>(), nblk, d_out0, d_out1);
+    k_ip_partial<1><<<grid, 256, 0, C.stream>>>(d_a, d_b, p0, p1, n, d_partial);
+    k_ip_final<1><<<npairs, 256, 0, C.stream>>>(d_partial, nblk, d_out0, d_out1);
   } else {
-    k_ip_partial<0><<<grid, 256, 0, C.stream>>>(d_sc, p0, p1, n, C.st_ip.as<uint32_t>());
-    k_ip_final<0><<<npairs, 256, 0, C.stream>>>(C.st_ip.as<uint32_t>(), nblk, d_out0, d_out1);
+    k_ip_partial<0><<<grid, 256, 0, C.stream>>>(d_a, d_b, p0, p1, n, d_partial);
+    k_ip_final<0><<<npairs, 256, 0, C.stream>>>(d_partial, nblk, d_out0, d_out1);
   }
   HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
+}
+int ip_launch(int curve, const uint32_t* d_a, const uint32_t* d_b, IpPair p0, IpPair p1, int npairs, uint32_t n,
+              uint32_t* d_out0, uint32_t* d_out1) {
+  TRY(cx().st_ip.ensure((size_t)2 * ip_blocks(n) * 32));
+  return ip_launch_with(curve, d_a, d_b, p0, p1, npairs, n, cx().st_ip.as<uint32_t>(), d_out0, d_out1);
 }
 
 FoldScalars make_fold_scalars(const uint64_t lo[4], const uint64_t hi[4]) {
@@ -566,17 +666,24 @@ int fold_scalars_launch(int curve, uint32_t* v0, uint32_t* o0, const FoldScalars
                         const FoldScalars& s1, int nvec, uint32_t n) {
   if (n == 0) return 0;
   uint32_t gx = cdiv(n, 256);
-  const uint32_t cap = (uint32_t)g_ctx.num_cus * 16;
+  const uint32_t cap = (uint32_t)cx().num_cus * 16;
   if (gx > cap) gx = cap;
   dim3 grid(gx, nvec);
-  HIP_TRY(hipEventRecord(g_ctx.op_ev[0], g_ctx.stream));
+  HIP_TRY(hipEventRecord(cx().op_ev[0], cx().stream));
   if (curve == BPGPU_PALLAS)
-    k_fold_scalars<1><<<grid, 256, 0, g_ctx.stream>>>(v0, o0, s0, v1, o1, s1, n);
+    k_fold_scalars<1><<<grid, 256, 0, cx().stream>>>(v0, o0, s0, v1, o1, s1, n);
   else
-    k_fold_scalars<0><<<grid, 256, 0, g_ctx.stream>>>(v0, o0, s0, v1, o1, s1, n);
-  HIP_TRY(hipEventRecord(g_ctx.op_ev[1], g_ctx.stream));
+    k_fold_scalars<0><<<grid, 256, 0, cx().stream>>>(v0, o0, s0, v1, o1, s1, n);
+  HIP_TRY(hipEventRecord(cx().op_ev[1], cx().stream));
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+// non-zero 4-bit codes among the first len positions of a recoding (= mixed additions a lane performs)
+inline uint32_t count_codes(const uint32_t* codes, int len) {
+  uint32_t c = 0;
+  for (int pos = 0; pos < len; pos++) c += ((codes[pos >> 3] >> ((pos & 7) * 4)) & 7u) != 0;
+  return c;
 }
 
 // ---- recoding of the two fold multipliers (shared by every lane of k_fold_points) -------------
@@ -713,26 +820,29 @@ int fold_points_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64
                        const uint32_t* g1, uint32_t* o1, const uint64_t lo1[4], const uint64_t hi1[4], int nvec,
                        uint32_t n) {
   if (n == 0) return 0;
-  Ctx& C = g_ctx;
-  FoldPlan plans[2];
+  Ctx& C = cx();
+  Plans2<FoldPlan> plans;  // kernel arguments
   if (curve == BPGPU_PALLAS) {
-    TRY(make_fold_plan<0>(lo0, hi0, plans[0]));
-    TRY(make_fold_plan<0>(nvec > 1 ? lo1 : lo0, nvec > 1 ? hi1 : hi0, plans[1]));
+    TRY(make_fold_plan<0>(lo0, hi0, plans.p[0]));
+    TRY(make_fold_plan<0>(nvec > 1 ? lo1 : lo0, nvec > 1 ? hi1 : hi0, plans.p[1]));
   } else {
-    TRY(make_fold_plan<1>(lo0, hi0, plans[0]));
-    TRY(make_fold_plan<1>(nvec > 1 ? lo1 : lo0, nvec > 1 ? hi1 : hi0, plans[1]));
+    TRY(make_fold_plan<1>(lo0, hi0, plans.p[0]));
+    TRY(make_fold_plan<1>(nvec > 1 ? lo1 : lo0, nvec > 1 ? hi1 : hi0, plans.p[1]));
   }
-  // the plans travel through a small device buffer (stream-ordered copy from pinned-by-value staging)
-  TRY(C.fold_plans.ensure(sizeof plans));
-  HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
-  HIP_TRY(upload_async(C.fold_plans.p, plans, sizeof plans, C.stream));
-  HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
+  C.fold_ops[0] = C.fold_ops[1] = C.fold_ops[2] = 0;
+  C.fold_ops[3] = 3;
+  for (int v = 0; v < nvec; v++) {
+    const FoldPlan& f = plans.p[v];
+    C.fold_ops[0] += n;
+    C.fold_ops[1] += (uint64_t)n * f.len;
+    C.fold_ops[2] += (uint64_t)n * (count_codes(f.codes_p, f.len) + count_codes(f.codes_q, f.len));
+  }
   dim3 grid(cdiv(n, 64), nvec);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
   if (curve == BPGPU_PALLAS)
-    k_fold_points<0><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<FoldPlan>(), n);
+    k_fold_points<0><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, plans, n);
   else
-    k_fold_points<1><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, C.fold_plans.as<FoldPlan>(), n);
+    k_fold_points<1><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, plans, n);
   HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -848,25 +958,28 @@ int fold_monic_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64_
 int fold_monic_pq(int curve, const uint32_t* p0, const uint32_t* q0, uint32_t* o0, const uint64_t s0[4], const uint32_t* p1,
                   const uint32_t* q1, uint32_t* o1, const uint64_t s1[4], int nvec, uint32_t n, int has_p) {
   if (n == 0) return 0;
-  Ctx& C = g_ctx;
-  MonicPlan plans[2];
+  Ctx& C = cx();
+  Plans2<MonicPlan> plans;  // kernel arguments
   if (curve == BPGPU_PALLAS) {
-    TRY(make_monic_plan<0>(s0, plans[0]));
-    TRY(make_monic_plan<0>(nvec > 1 ? s1 : s0, plans[1]));
+    TRY(make_monic_plan<0>(s0, plans.p[0]));
+    TRY(make_monic_plan<0>(nvec > 1 ? s1 : s0, plans.p[1]));
   } else {
-    TRY(make_monic_plan<1>(s0, plans[0]));
-    TRY(make_monic_plan<1>(nvec > 1 ? s1 : s0, plans[1]));
+    TRY(make_monic_plan<1>(s0, plans.p[0]));
+    TRY(make_monic_plan<1>(nvec > 1 ? s1 : s0, plans.p[1]));
   }
-  TRY(C.fold_plans.ensure(sizeof(FoldPlan) * 2));
-  HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
-  HIP_TRY(upload_async(C.fold_plans.p, plans, sizeof plans, C.stream));
-  HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
+  C.fold_ops[0] = C.fold_ops[1] = C.fold_ops[2] = 0;
+  C.fold_ops[3] = 1;
+  for (int v = 0; v < nvec; v++) {
+    C.fold_ops[0] += n;
+    C.fold_ops[1] += (uint64_t)n * plans.p[v].len;
+    C.fold_ops[2] += (uint64_t)n * (count_codes(plans.p[v].codes, plans.p[v].len) + (has_p ? 1u : 0u));
+  }
   dim3 grid(cdiv(n, 256), nvec);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
   if (curve == BPGPU_PALLAS)
-    k_fold_monic<0><<<grid, 256, 0, C.stream>>>(p0, q0, o0, p1, q1, o1, C.fold_plans.as<MonicPlan>(), n, has_p);
+    k_fold_monic<0><<<grid, 256, 0, C.stream>>>(p0, q0, o0, p1, q1, o1, plans, n, has_p);
   else
-    k_fold_monic<1><<<grid, 256, 0, C.stream>>>(p0, q0, o0, p1, q1, o1, C.fold_plans.as<MonicPlan>(), n, has_p);
+    k_fold_monic<1><<<grid, 256, 0, C.stream>>>(p0, q0, o0, p1, q1, o1, plans, n, has_p);
   HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -881,6 +994,8 @@ size_t pow2_at_least(size_t n) {
 }  // namespace
 
 struct bpgpu_ipa {
+  Ctx* ctx;     // the context the session was opened on; every later call runs there
+  bool failed;  // a call failed half-way through a round: the state is undefined, every later call is refused
   int curve;
   size_t np;   // padded original length
   size_t len;  // current vector length
@@ -989,27 +1104,32 @@ int ipa_fold_generators(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv[
 // out[i] = g[i] + s[0] g[i+q] + s[1] g[i+2q] + s[2] g[i+3q] for both generator vectors (multipliers in ark form)
 int fold_joint4_launch(int curve, uint32_t* gA, const uint64_t sA[3][4], uint32_t* gB, const uint64_t sB[3][4], uint32_t q) {
   if (q == 0) return 0;
-  Ctx& C = g_ctx;
-  static_assert(sizeof(Joint4Plan) * 2 <= 4096, "plan buffer");
-  Joint4Plan plans[2];
+  Ctx& C = cx();
+  static_assert(sizeof(Plans2<Joint4Plan>) <= 1024, "kernel arguments");
+  Plans2<Joint4Plan> plans;
   for (int v = 0; v < 2; v++) {
-    plans[v].len = 0;
+    plans.p[v].len = 0;
     for (int t = 0; t < 3; t++) {
       const uint64_t* m = v == 0 ? sA[t] : sB[t];
-      if (curve == BPGPU_PALLAS) TRY(make_monic_plan<0>(m, plans[v].m[t])); else TRY(make_monic_plan<1>(m, plans[v].m[t]));
-      if (plans[v].m[t].len > plans[v].len) plans[v].len = plans[v].m[t].len;
+      if (curve == BPGPU_PALLAS) TRY(make_monic_plan<0>(m, plans.p[v].m[t])); else TRY(make_monic_plan<1>(m, plans.p[v].m[t]));
+      if (plans.p[v].m[t].len > plans.p[v].len) plans.p[v].len = plans.p[v].m[t].len;
     }
   }
-  TRY(C.fold_plans.ensure(4096));
-  HIP_TRY(hipStreamSynchronize(C.stream));  // the previous launch may still read the buffer
-  HIP_TRY(upload_async(C.fold_plans.p, plans, sizeof plans, C.stream));
-  HIP_TRY(hipStreamSynchronize(C.stream));  // plans[] lives on this stack frame
+  C.fold_ops[0] = 2ull * q;
+  C.fold_ops[1] = C.fold_ops[2] = 0;
+  C.fold_ops[3] = 2;
+  for (int v = 0; v < 2; v++) {
+    C.fold_ops[1] += (uint64_t)q * plans.p[v].len;
+    uint32_t adds = 1;
+    for (int t = 0; t < 3; t++) adds += count_codes(plans.p[v].m[t].codes, plans.p[v].m[t].len);
+    C.fold_ops[2] += (uint64_t)q * adds;
+  }
   dim3 grid(cdiv(q, 256), 2);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
   if (curve == BPGPU_PALLAS)
-    k_fold_joint4<0><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, C.fold_plans.as<Joint4Plan>(), q);
+    k_fold_joint4<0><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);
   else
-    k_fold_joint4<1><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, C.fold_plans.as<Joint4Plan>(), q);
+    k_fold_joint4<1><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);
   HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1062,9 +1182,9 @@ int ipa_freeze(bpgpu_ipa* s) {
   const uint32_t half = (uint32_t)s->freeze_cap;
   FoldScalars m = make_fold_scalars(s->muA, s->muB);
   if (s->curve == BPGPU_PALLAS)
-    k_frozen_init<1><<<cdiv(2 * half, 256), 256, 0, g_ctx.stream>>>(s->wA(), half, m);
+    k_frozen_init<1><<<cdiv(2 * half, 256), 256, 0, cx().stream>>>(s->wA(), half, m);
   else
-    k_frozen_init<0><<<cdiv(2 * half, 256), 256, 0, g_ctx.stream>>>(s->wA(), half, m);
+    k_frozen_init<0><<<cdiv(2 * half, 256), 256, 0, cx().stream>>>(s->wA(), half, m);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1101,132 +1221,164 @@ extern "C" {
 
 const char* bpgpu_last_error(void) { return g_err.c_str(); }
 
-int bpgpu_init(int device) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_ctx.ready) {
-    if (g_ctx.device != device) return fail(BPGPU_E_ARG, "already initialised on device %d", g_ctx.device);
-    return 0;
-  }
+// ---- contexts ------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+// caller holds C.mu (or is the only one who can see C)
+int ctx_init(Ctx& C, int device) {
   int count = 0;
   HIP_TRY(hipGetDeviceCount(&count));
   if (device < 0 || device >= count) return fail(BPGPU_E_ARG, "device %d out of range (%d visible)", device, count);
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-  for (auto& e : g_ctx.ev) HIP_TRY(hipEventCreate(&e));
-  for (auto& e : g_ctx.op_ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+  for (auto& e : C.ev) HIP_TRY(hipEventCreate(&e));
+  for (auto& e : C.op_ev) HIP_TRY(hipEventCreate(&e));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
-  g_ctx.num_cus = prop.multiProcessorCount;
-  g_ctx.device = device;
-  g_ctx.helper.start();
-  g_ctx.ready = true;
+  C.num_cus = prop.multiProcessorCount;
+  C.device = device;
+  C.helper.start();
+  C.ready = true;
   return 0;
 }
 
-void bpgpu_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx.ready) return;
-  (void)hipSetDevice(g_ctx.device);
-  (void)hipStreamSynchronize(g_ctx.stream);
-  for (DevBuf* b : {&g_ctx.counts, &g_ctx.offs, &g_ctx.order, &g_ctx.cursor, &g_ctx.canon, &g_ctx.ent_idx, &g_ctx.ent_fine, &g_ctx.sorted, &g_ctx.bsum, &g_ctx.partial, &g_ctx.heavy, &g_ctx.bcount, &g_ctx.redtmp,
-                    &g_ctx.winsum, &g_ctx.st_pts_in, &g_ctx.st_pts, &g_ctx.st_sc, &g_ctx.st_out, &g_ctx.st_ip, &g_ctx.fold_plans})
+void ctx_release(Ctx& C) {
+  if (!C.ready) return;
+  (void)hipSetDevice(C.device);
+  (void)hipStreamSynchronize(C.stream);
+  for (DevBuf* b : {&C.counts, &C.offs, &C.order, &C.cursor, &C.canon, &C.ent_idx, &C.ent_fine, &C.sorted, &C.bsum, &C.partial,
+                    &C.heavy, &C.bcount, &C.redtmp, &C.winsum, &C.st_pts_in, &C.st_pts, &C.st_sc, &C.st_out, &C.st_ip})
     b->release();
-  for (DevBuf& b : g_ctx.aux) b.release();
-  g_ctx.ipa_pts.release();
-  g_ctx.ipa_sc.release();
-  g_ctx.ipa_pool_busy = false;
-  g_ctx.h_winsum.release();
-  g_ctx.up.release();
-  g_ctx.helper.stop();
-  for (auto& e : g_ctx.ev) (void)hipEventDestroy(e);
-  for (auto& e : g_ctx.op_ev) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(g_ctx.stream);
-  g_ctx.ready = false;
+  for (DevBuf& b : C.aux) b.release();
+  C.ipa_pts.release();
+  C.ipa_sc.release();
+  C.ipa_pool_busy = false;
+  C.h_winsum.release();
+  C.up.release();
+  C.helper.stop();
+  for (auto& e : C.ev) (void)hipEventDestroy(e);
+  for (auto& e : C.op_ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(C.stream);
+  C.ready = false;
+}
+}  // namespace
+
+extern "C" {
+
+int bpgpu_init(int device) {
+  std::lock_guard<std::mutex> lk(g_primary.mu);
+  if (g_primary.ready) {
+    if (g_primary.device != device) return fail(BPGPU_E_ARG, "already initialised on device %d", g_primary.device);
+    return 0;
+  }
+  return ctx_init(g_primary, device);
+}
+
+// Open IPA sessions keep device memory of their context: shutting down under them would leave them with
+// dangling pointers, so the call is refused (returns without releasing anything) until they are freed.
+void bpgpu_shutdown(void) {
+  std::lock_guard<std::mutex> reg(g_reg_mu);
+  {
+    std::lock_guard<std::mutex> lk(g_primary.mu);
+    if (g_primary.open_sessions > 0) {
+      (void)fail(BPGPU_E_STATE, "bpgpu_shutdown: %d IPA session(s) still open; free them first", g_primary.open_sessions);
+      return;
+    }
+  }
+  g_shard_pool.stop();
+  for (auto& c : g_shards) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    ctx_release(*c);
+  }
+  g_shards.clear();
+  std::lock_guard<std::mutex> lk(g_primary.mu);
+  ctx_release(g_primary);
 }
 
 int bpgpu_set_window_bits(int c) {
   if (c != 0 && (c < 2 || c > 20)) return fail(BPGPU_E_ARG, "window bits %d outside [2, 20]", c);
-  g_ctx.window_bits = c;
+  g_window_bits.store(c);
   return 0;
 }
 
 int bpgpu_set_freeze_len(size_t len) {
   if (len > (1u << 24)) return fail(BPGPU_E_ARG, "freeze length too large");
-  g_ctx.freeze_len = len;
+  g_freeze_len.store(len);
   return 0;
 }
 
 int bpgpu_set_pair_fold(int enable) {
-  g_ctx.pair_fold = enable != 0;
+  g_pair_fold.store(enable != 0);
   return 0;
 }
 
 int bpgpu_dev_alloc(size_t bytes, void** dptr) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   if (!dptr) return fail(BPGPU_E_ARG, "null output pointer");
-  HIP_TRY(hipSetDevice(g_ctx.device));
+  HIP_TRY(hipSetDevice(cx().device));
   HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
   return 0;
 }
 int bpgpu_dev_free(void* dptr) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   HIP_TRY(hipFree(dptr));
   return 0;
 }
 int bpgpu_dev_upload(void* dptr, const void* host, size_t bytes) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   if (bytes == 0) return 0;
-  HIP_TRY(upload_async(dptr, host, bytes, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(upload_async(dptr, host, bytes, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 int bpgpu_dev_download(void* host, const void* dptr, size_t bytes) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   if (bytes == 0) return 0;
-  HIP_TRY(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_points_to_device(int curve, const uint64_t* points, size_t n, int fmt, void* d_out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (fmt != 0 && fmt != 1) return fail(BPGPU_E_ARG, "fmt must be 0 (jacobian) or 1 (affine)");
   if (n == 0) return 0;
   if (!points || !d_out) return fail(BPGPU_E_ARG, "null pointer");
   size_t bytes = n * (fmt == 0 ? 96 : 64);
-  TRY(g_ctx.st_pts_in.ensure(bytes));
-  HIP_TRY(upload_async(g_ctx.st_pts_in.p, points, bytes, g_ctx.stream));
-  TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), (uint32_t*)d_out, n, fmt));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  TRY(cx().st_pts_in.ensure(bytes));
+  HIP_TRY(upload_async(cx().st_pts_in.p, points, bytes, cx().stream));
+  TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), (uint32_t*)d_out, n, fmt));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_points_from_device(int curve, const void* d_points, size_t n, uint64_t* out_xyz) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (n == 0) return 0;
   if (!d_points || !out_xyz) return fail(BPGPU_E_ARG, "null pointer");
-  TRY(g_ctx.st_out.ensure(n * 96));
-  TRY(points_out(curve, (const uint32_t*)d_points, g_ctx.st_out.as<uint32_t>(), n));
-  HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_out.p, n * 96, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  TRY(cx().st_out.ensure(n * 96));
+  TRY(points_out(curve, (const uint32_t*)d_points, cx().st_out.as<uint32_t>(), n));
+  HIP_TRY(hipMemcpyAsync(out_xyz, cx().st_out.p, n * 96, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_msm_device(int curve, const void* d_points, const void* d_scalars, size_t n, uint64_t out_xy_inf[9]) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  if (n > BPGPU_MSM_MAX_N) return fail(BPGPU_E_ARG, "n = %zu: one MSM call takes at most 2^28 points", n);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (!out_xy_inf) return fail(BPGPU_E_ARG, "null output");
-  if (n > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n && (!d_points || !d_scalars)) return fail(BPGPU_E_ARG, "null pointer");
   return msm_dispatch(curve, (const uint32_t*)d_points, (const uint32_t*)d_scalars, single_plan((uint32_t)n),
                       (uint64_t(*)[9])out_xy_inf);
@@ -1234,22 +1386,22 @@ int bpgpu_msm_device(int curve, const void* d_points, const void* d_scalars, siz
 
 static int msm_host(int curve, const uint64_t* points, int fmt, const uint64_t* scalars, size_t n,
                     uint64_t out_xy_inf[9]) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  if (n > BPGPU_MSM_MAX_N) return fail(BPGPU_E_ARG, "n = %zu: one MSM call takes at most 2^28 points", n);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (!out_xy_inf) return fail(BPGPU_E_ARG, "null output");
-  if (n > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n && (!points || !scalars)) return fail(BPGPU_E_ARG, "null pointer");
   if (n) {
     size_t pbytes = n * (fmt == 0 ? 96 : 64);
-    TRY(g_ctx.st_pts_in.ensure(pbytes));
-    TRY(g_ctx.st_pts.ensure(n * 64));
-    TRY(g_ctx.st_sc.ensure(n * 32));
-    HIP_TRY(upload_async(g_ctx.st_pts_in.p, points, pbytes, g_ctx.stream));
-    HIP_TRY(upload_async(g_ctx.st_sc.p, scalars, n * 32, g_ctx.stream));
-    TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), g_ctx.st_pts.as<uint32_t>(), n, fmt));
+    TRY(cx().st_pts_in.ensure(pbytes));
+    TRY(cx().st_pts.ensure(n * 64));
+    TRY(cx().st_sc.ensure(n * 32));
+    HIP_TRY(upload_async(cx().st_pts_in.p, points, pbytes, cx().stream));
+    HIP_TRY(upload_async(cx().st_sc.p, scalars, n * 32, cx().stream));
+    TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), cx().st_pts.as<uint32_t>(), n, fmt));
   }
-  return msm_dispatch(curve, g_ctx.st_pts.as<uint32_t>(), g_ctx.st_sc.as<uint32_t>(), single_plan((uint32_t)n),
+  return msm_dispatch(curve, cx().st_pts.as<uint32_t>(), cx().st_sc.as<uint32_t>(), single_plan((uint32_t)n),
                       (uint64_t(*)[9])out_xy_inf);
 }
 
@@ -1262,57 +1414,47 @@ int bpgpu_msm_affine(int curve, const uint64_t* points_xy, const uint64_t* scala
 }
 
 int bpgpu_ip_device(int curve, const void* d_a, const void* d_b, size_t n, uint64_t out[4]) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  if (n > 0xffffffffu) return fail(BPGPU_E_ARG, "n too large");
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (!out) return fail(BPGPU_E_ARG, "null output");
-  if (n > 0xffffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n && (!d_a || !d_b)) return fail(BPGPU_E_ARG, "null pointer");
-  TRY(g_ctx.st_out.ensure(64));
-  // element offsets are relative to d_a; b is addressed through a second base by pointer difference
-  const uint32_t* base = (const uint32_t*)d_a;
-  ptrdiff_t diff = ((const uint8_t*)d_b - (const uint8_t*)d_a);
-  if (diff % 32 != 0 || diff / 32 < 0 || diff / 32 > 0xffffffffll) {
-    // unrelated allocations: stage b next to a copy of a
-    TRY(g_ctx.st_sc.ensure(2 * n * 32 + 32));
-    HIP_TRY(hipMemcpyAsync(g_ctx.st_sc.p, d_a, n * 32, hipMemcpyDeviceToDevice, g_ctx.stream));
-    HIP_TRY(hipMemcpyAsync((uint8_t*)g_ctx.st_sc.p + n * 32, d_b, n * 32, hipMemcpyDeviceToDevice, g_ctx.stream));
-    base = g_ctx.st_sc.as<uint32_t>();
-    diff = (ptrdiff_t)n * 32;
-  }
-  IpPair p0{0u, (uint32_t)(diff / 32)};
-  TRY(ip_launch(curve, base, p0, p0, 1, (uint32_t)n, g_ctx.st_out.as<uint32_t>(), g_ctx.st_out.as<uint32_t>() + 8));
-  HIP_TRY(hipMemcpyAsync(out, g_ctx.st_out.p, 32, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  TRY(cx().st_out.ensure(64));
+  IpPair p0{0u, 0u};
+  TRY(ip_launch(curve, (const uint32_t*)d_a, (const uint32_t*)d_b, p0, p0, 1, (uint32_t)n, cx().st_out.as<uint32_t>(),
+                cx().st_out.as<uint32_t>() + 8));
+  HIP_TRY(hipMemcpyAsync(out, cx().st_out.p, 32, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_ip(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
   {
-    std::lock_guard<std::mutex> lk(g_mu);
+    CtxLock lk;
     TRY(check_ready());
     TRY(check_curve(curve));
     if (!out) return fail(BPGPU_E_ARG, "null output");
     if (n > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
     if (n && (!a || !b)) return fail(BPGPU_E_ARG, "null pointer");
-    TRY(g_ctx.st_sc.ensure(2 * n * 32 + 32));
-    TRY(g_ctx.st_out.ensure(64));
+    TRY(cx().st_sc.ensure(2 * n * 32 + 32));
+    TRY(cx().st_out.ensure(64));
     if (n) {
-      HIP_TRY(upload_async(g_ctx.st_sc.p, a, n * 32, g_ctx.stream));
-      HIP_TRY(upload_async((uint8_t*)g_ctx.st_sc.p + n * 32, b, n * 32, g_ctx.stream));
+      HIP_TRY(upload_async(cx().st_sc.p, a, n * 32, cx().stream));
+      HIP_TRY(upload_async((uint8_t*)cx().st_sc.p + n * 32, b, n * 32, cx().stream));
     }
     IpPair p0{0u, (uint32_t)n};
-    TRY(ip_launch(curve, g_ctx.st_sc.as<uint32_t>(), p0, p0, 1, (uint32_t)n, g_ctx.st_out.as<uint32_t>(),
-                  g_ctx.st_out.as<uint32_t>() + 8));
-    HIP_TRY(hipMemcpyAsync(out, g_ctx.st_out.p, 32, hipMemcpyDeviceToHost, g_ctx.stream));
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    TRY(ip_launch(curve, cx().st_sc.as<uint32_t>(), cx().st_sc.as<uint32_t>(), p0, p0, 1, (uint32_t)n,
+                  cx().st_out.as<uint32_t>(), cx().st_out.as<uint32_t>() + 8));
+    HIP_TRY(hipMemcpyAsync(out, cx().st_out.p, 32, hipMemcpyDeviceToHost, cx().stream));
+    HIP_TRY(hipStreamSynchronize(cx().stream));
   }
   return 0;
 }
 
 int bpgpu_fold_scalars_device(int curve, const void* d_v, size_t n_out, const uint64_t s_lo[4],
                               const uint64_t s_hi[4], void* d_out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (n_out > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
@@ -1320,59 +1462,59 @@ int bpgpu_fold_scalars_device(int curve, const void* d_v, size_t n_out, const ui
   FoldScalars f = make_fold_scalars(s_lo, s_hi);
   TRY(fold_scalars_launch(curve, (uint32_t*)d_v, (uint32_t*)d_out, f, (uint32_t*)d_v, (uint32_t*)d_out, f, 1,
                           (uint32_t)n_out));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_fold_scalars(int curve, const uint64_t* v, size_t n_out, const uint64_t s_lo[4], const uint64_t s_hi[4],
                        uint64_t* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (n_out > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n_out == 0) return 0;
   if (!v || !out || !s_lo || !s_hi) return fail(BPGPU_E_ARG, "null pointer");
-  TRY(g_ctx.st_sc.ensure(2 * n_out * 32));
-  HIP_TRY(upload_async(g_ctx.st_sc.p, v, 2 * n_out * 32, g_ctx.stream));
+  TRY(cx().st_sc.ensure(2 * n_out * 32));
+  HIP_TRY(upload_async(cx().st_sc.p, v, 2 * n_out * 32, cx().stream));
   FoldScalars f = make_fold_scalars(s_lo, s_hi);
-  uint32_t* d = g_ctx.st_sc.as<uint32_t>();
+  uint32_t* d = cx().st_sc.as<uint32_t>();
   TRY(fold_scalars_launch(curve, d, d, f, d, d, f, 1, (uint32_t)n_out));
-  HIP_TRY(hipMemcpyAsync(out, d, n_out * 32, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(out, d, n_out * 32, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_fold_points_device(int curve, const void* d_g, size_t n_out, const uint64_t s_lo[4],
                              const uint64_t s_hi[4], void* d_out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (n_out > 0x7fffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n_out && (!d_g || !d_out || !s_lo || !s_hi)) return fail(BPGPU_E_ARG, "null pointer");
   TRY(fold_points_launch(curve, (const uint32_t*)d_g, (uint32_t*)d_out, s_lo, s_hi, (const uint32_t*)d_g,
                          (uint32_t*)d_out, s_lo, s_hi, 1, (uint32_t)n_out));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_fold_points(int curve, const uint64_t* g_xyz, size_t n_out, const uint64_t s_lo[4], const uint64_t s_hi[4],
                       uint64_t* out_xyz) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (n_out > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n_out == 0) return 0;
   if (!g_xyz || !out_xyz || !s_lo || !s_hi) return fail(BPGPU_E_ARG, "null pointer");
   size_t n2 = 2 * n_out;
-  TRY(g_ctx.st_pts_in.ensure(n2 * 96));
-  TRY(g_ctx.st_pts.ensure(n2 * 64));
-  HIP_TRY(upload_async(g_ctx.st_pts_in.p, g_xyz, n2 * 96, g_ctx.stream));
-  TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), g_ctx.st_pts.as<uint32_t>(), n2, 0));
-  uint32_t* d = g_ctx.st_pts.as<uint32_t>();
+  TRY(cx().st_pts_in.ensure(n2 * 96));
+  TRY(cx().st_pts.ensure(n2 * 64));
+  HIP_TRY(upload_async(cx().st_pts_in.p, g_xyz, n2 * 96, cx().stream));
+  TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), cx().st_pts.as<uint32_t>(), n2, 0));
+  uint32_t* d = cx().st_pts.as<uint32_t>();
   TRY(fold_points_launch(curve, d, d, s_lo, s_hi, d, d, s_lo, s_hi, 1, (uint32_t)n_out));
-  TRY(points_out(curve, d, g_ctx.st_pts_in.as<uint32_t>(), n_out));
-  HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_pts_in.p, n_out * 96, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  TRY(points_out(curve, d, cx().st_pts_in.as<uint32_t>(), n_out));
+  HIP_TRY(hipMemcpyAsync(out_xyz, cx().st_pts_in.p, n_out * 96, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
@@ -1416,12 +1558,13 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
                       const void* d_a, const void* d_b, const void* d_q, size_t n, const uint64_t* ls_xyz,
                       const uint64_t* rs_xyz, size_t k, const uint64_t* challenges, const uint64_t final_a[4],
                       const uint64_t final_b[4], uint64_t out_xy_inf[9]) {
-  Ctx& C = g_ctx;
+  Ctx& C = cx();
   const bool from_device = d_q != nullptr;
   if (k > 30) return fail(BPGPU_E_ARG, "too many rounds");
   const size_t np = (size_t)1 << k;
   if (pow2_at_least(n < 1 ? 1 : n) != np) return fail(BPGPU_E_ARG, "proof has %zu rounds but the generators need %zu elements", k, n);
   const size_t total = 2 * np + 1 + 2 * k;
+  if (total > BPGPU_MSM_MAX_N) return fail(BPGPU_E_ARG, "verifier MSM of %zu points: at most 2^28", total);
   std::vector<uint64_t> tab, tail;
   TRY(curve == BPGPU_PALLAS ? verify_tables<1>(challenges, k, final_a, final_b, tab, tail)
                             : verify_tables<0>(challenges, k, final_a, final_b, tab, tail));
@@ -1488,7 +1631,7 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
 int bpgpu_ipa_verify_msm(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
                          size_t n, const uint64_t* ls_xyz, const uint64_t* rs_xyz, size_t k, const uint64_t* challenges,
                          const uint64_t final_a[4], const uint64_t final_b[4], uint64_t out_xy_inf[9]) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (!ip_gen_xyz || !final_a || !final_b || !out_xy_inf) return fail(BPGPU_E_ARG, "null pointer");
@@ -1501,7 +1644,7 @@ int bpgpu_ipa_verify_msm(int curve, const uint64_t* a_gens_xyz, const uint64_t* 
 int bpgpu_ipa_verify_msm_device(int curve, const void* d_a_gens, const void* d_b_gens, const void* d_ip_gen, size_t n,
                                 const uint64_t* ls_xyz, const uint64_t* rs_xyz, size_t k, const uint64_t* challenges,
                                 const uint64_t final_a[4], const uint64_t final_b[4], uint64_t out_xy_inf[9]) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (!d_ip_gen || !final_a || !final_b || !out_xy_inf) return fail(BPGPU_E_ARG, "null pointer");
@@ -1531,7 +1674,7 @@ bool geometric_from_one(const uint64_t* y, size_t k) {
 }
 
 int fold_scalars_kary_launch(int curve, const uint32_t* d_v, size_t ck, size_t k, const uint64_t* y, uint32_t* d_out) {
-  Ctx& C = g_ctx;
+  Ctx& C = cx();
   if (k > 1024) return fail(BPGPU_E_ARG, "k = %zu chunks: at most 1024 are supported", k);
   if (ck == 0) return 0;
   if (k == 0) {  // sum_vecs over no summands: vec![zero; len]
@@ -1557,7 +1700,7 @@ int fold_scalars_kary_launch(int curve, const uint32_t* d_v, size_t ck, size_t k
 // multiplication per chunk (k_fold_monic); when y = (1, r, r^2, ...) -- the only shape the reference
 // uses, powers(x, 0..k) -- Horner's rule needs k - 1 of them:  G_0 + r (G_1 + r (G_2 + ...)).
 int fold_points_kary_launch(int curve, const uint32_t* d_g, size_t ck, size_t k, const uint64_t* y, uint32_t* d_out) {
-  Ctx& C = g_ctx;
+  Ctx& C = cx();
   if (ck == 0) return 0;
   if (k == 0) {
     HIP_TRY(hipMemsetAsync(d_out, 0, ck * 64, C.stream));  // identity points
@@ -1581,34 +1724,34 @@ int fold_points_kary_launch(int curve, const uint32_t* d_g, size_t ck, size_t k,
 }  // extern "C++"
 
 int bpgpu_fold_scalars_kary_device(int curve, const void* d_v, size_t ck, size_t k, const uint64_t* y, void* d_out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (ck > 0x7fffffffu || ck * (k ? k : 1) > 0xffffffffull) return fail(BPGPU_E_ARG, "vector too large");
   if (ck && (!d_out || (k && (!d_v || !y)))) return fail(BPGPU_E_ARG, "null pointer");
   TRY(fold_scalars_kary_launch(curve, (const uint32_t*)d_v, ck, k, y, (uint32_t*)d_out));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_fold_scalars_kary(int curve, const uint64_t* v, size_t ck, size_t k, const uint64_t* y, uint64_t* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (ck > 0x7fffffffu || ck * (k ? k : 1) > 0x3fffffffull) return fail(BPGPU_E_ARG, "vector too large");
   if (ck == 0) return 0;
   if (!out || (k && (!v || !y))) return fail(BPGPU_E_ARG, "null pointer");
-  TRY(g_ctx.st_sc.ensure((k ? k : 1) * ck * 32));
-  if (k) HIP_TRY(upload_async(g_ctx.st_sc.p, v, k * ck * 32, g_ctx.stream));
-  uint32_t* d = g_ctx.st_sc.as<uint32_t>();
+  TRY(cx().st_sc.ensure((k ? k : 1) * ck * 32));
+  if (k) HIP_TRY(upload_async(cx().st_sc.p, v, k * ck * 32, cx().stream));
+  uint32_t* d = cx().st_sc.as<uint32_t>();
   TRY(fold_scalars_kary_launch(curve, d, ck, k, y, d));
-  HIP_TRY(hipMemcpyAsync(out, d, ck * 32, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(out, d, ck * 32, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_fold_points_kary_device(int curve, const void* d_g, size_t ck, size_t k, const uint64_t* y, void* d_out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (ck > 0x7fffffffu || ck * (k ? k : 1) > 0x7fffffffull) return fail(BPGPU_E_ARG, "vector too large");
@@ -1618,101 +1761,101 @@ int bpgpu_fold_points_kary_device(int curve, const void* d_g, size_t ck, size_t 
     if (o0 < g0 + k * ck * 64 && g0 < o0 + ck * 64) return fail(BPGPU_E_ARG, "d_out overlaps d_g");
   }
   TRY(fold_points_kary_launch(curve, (const uint32_t*)d_g, ck, k, y, (uint32_t*)d_out));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_fold_points_kary(int curve, const uint64_t* g_xyz, size_t ck, size_t k, const uint64_t* y, uint64_t* out_xyz) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (ck > 0x7fffffffu || ck * (k ? k : 1) > 0x3fffffffull) return fail(BPGPU_E_ARG, "vector too large");
   if (ck == 0) return 0;
   if (!out_xyz || (k && (!g_xyz || !y))) return fail(BPGPU_E_ARG, "null pointer");
   const size_t tot = k * ck;
-  TRY(g_ctx.st_pts_in.ensure((tot > ck ? tot : ck) * 96));
-  TRY(g_ctx.st_pts.ensure((tot + ck) * 64));
-  uint32_t* d = g_ctx.st_pts.as<uint32_t>();
+  TRY(cx().st_pts_in.ensure((tot > ck ? tot : ck) * 96));
+  TRY(cx().st_pts.ensure((tot + ck) * 64));
+  uint32_t* d = cx().st_pts.as<uint32_t>();
   uint32_t* d_o = d + 16ull * tot;
   if (tot) {
-    HIP_TRY(upload_async(g_ctx.st_pts_in.p, g_xyz, tot * 96, g_ctx.stream));
-    TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), d, tot, 0));
+    HIP_TRY(upload_async(cx().st_pts_in.p, g_xyz, tot * 96, cx().stream));
+    TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), d, tot, 0));
   }
   TRY(fold_points_kary_launch(curve, d, ck, k, y, d_o));
-  TRY(points_out(curve, d_o, g_ctx.st_pts_in.as<uint32_t>(), ck));
-  HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_pts_in.p, ck * 96, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  TRY(points_out(curve, d_o, cx().st_pts_in.as<uint32_t>(), ck));
+  HIP_TRY(hipMemcpyAsync(out_xyz, cx().st_pts_in.p, ck * 96, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_hadamard(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (n > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n == 0) return 0;
   if (!a || !b || !out) return fail(BPGPU_E_ARG, "null pointer");
-  TRY(g_ctx.st_sc.ensure(2 * n * 32));
-  uint32_t* d = g_ctx.st_sc.as<uint32_t>();
-  HIP_TRY(upload_async(d, a, n * 32, g_ctx.stream));
-  HIP_TRY(upload_async(d + 8ull * n, b, n * 32, g_ctx.stream));
+  TRY(cx().st_sc.ensure(2 * n * 32));
+  uint32_t* d = cx().st_sc.as<uint32_t>();
+  HIP_TRY(upload_async(d, a, n * 32, cx().stream));
+  HIP_TRY(upload_async(d + 8ull * n, b, n * 32, cx().stream));
   uint32_t gx = cdiv(n, 256);
-  const uint32_t cap = (uint32_t)g_ctx.num_cus * 16;
+  const uint32_t cap = (uint32_t)cx().num_cus * 16;
   if (gx > cap) gx = cap;
   if (curve == BPGPU_PALLAS)
-    k_hadamard<1><<<gx, 256, 0, g_ctx.stream>>>(d, d + 8ull * n, d, (uint32_t)n);
+    k_hadamard<1><<<gx, 256, 0, cx().stream>>>(d, d + 8ull * n, d, (uint32_t)n);
   else
-    k_hadamard<0><<<gx, 256, 0, g_ctx.stream>>>(d, d + 8ull * n, d, (uint32_t)n);
+    k_hadamard<0><<<gx, 256, 0, cx().stream>>>(d, d + 8ull * n, d, (uint32_t)n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out, d, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(out, d, n * 32, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_hadamard_points(int curve, const uint64_t* bases_xyz, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (n > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n == 0) return 0;
   if (!bases_xyz || !scalars || !out_xyz) return fail(BPGPU_E_ARG, "null pointer");
-  TRY(g_ctx.st_pts_in.ensure(n * 96));
-  TRY(g_ctx.st_pts.ensure(n * 64));
-  TRY(g_ctx.st_sc.ensure(n * 32));
-  HIP_TRY(upload_async(g_ctx.st_pts_in.p, bases_xyz, n * 96, g_ctx.stream));
-  HIP_TRY(upload_async(g_ctx.st_sc.p, scalars, n * 32, g_ctx.stream));
-  uint32_t* d = g_ctx.st_pts.as<uint32_t>();
-  TRY(points_in(curve, g_ctx.st_pts_in.as<uint32_t>(), d, n, 0));
+  TRY(cx().st_pts_in.ensure(n * 96));
+  TRY(cx().st_pts.ensure(n * 64));
+  TRY(cx().st_sc.ensure(n * 32));
+  HIP_TRY(upload_async(cx().st_pts_in.p, bases_xyz, n * 96, cx().stream));
+  HIP_TRY(upload_async(cx().st_sc.p, scalars, n * 32, cx().stream));
+  uint32_t* d = cx().st_pts.as<uint32_t>();
+  TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), d, n, 0));
   if (curve == BPGPU_PALLAS)
-    k_hadamard_points<0><<<cdiv(n, 256), 256, 0, g_ctx.stream>>>(d, g_ctx.st_sc.as<uint32_t>(), d, (uint32_t)n);
+    k_hadamard_points<0><<<cdiv(n, 256), 256, 0, cx().stream>>>(d, cx().st_sc.as<uint32_t>(), d, (uint32_t)n);
   else
-    k_hadamard_points<1><<<cdiv(n, 256), 256, 0, g_ctx.stream>>>(d, g_ctx.st_sc.as<uint32_t>(), d, (uint32_t)n);
+    k_hadamard_points<1><<<cdiv(n, 256), 256, 0, cx().stream>>>(d, cx().st_sc.as<uint32_t>(), d, (uint32_t)n);
   HIP_TRY(hipGetLastError());
-  TRY(points_out(curve, d, g_ctx.st_pts_in.as<uint32_t>(), n));
-  HIP_TRY(hipMemcpyAsync(out_xyz, g_ctx.st_pts_in.p, n * 96, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  TRY(points_out(curve, d, cx().st_pts_in.as<uint32_t>(), n));
+  HIP_TRY(hipMemcpyAsync(out_xyz, cx().st_pts_in.p, n * 96, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_powers(int curve, const uint64_t f[4], uint64_t start, size_t n, uint64_t* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (n > 0x3fffffffu) return fail(BPGPU_E_ARG, "n too large");
   if (n == 0) return 0;
   if (!f || !out) return fail(BPGPU_E_ARG, "null pointer");
-  TRY(g_ctx.st_sc.ensure(n * 32));
+  TRY(cx().st_sc.ensure(n * 32));
   PowersArgs args;
   memcpy(args.f, f, 32);
   args.start = start;
   const uint32_t lanes = cdiv(n, 8);
   if (curve == BPGPU_PALLAS)
-    k_powers<1><<<cdiv(lanes, 256), 256, 0, g_ctx.stream>>>(args, g_ctx.st_sc.as<uint32_t>(), (uint32_t)n);
+    k_powers<1><<<cdiv(lanes, 256), 256, 0, cx().stream>>>(args, cx().st_sc.as<uint32_t>(), (uint32_t)n);
   else
-    k_powers<0><<<cdiv(lanes, 256), 256, 0, g_ctx.stream>>>(args, g_ctx.st_sc.as<uint32_t>(), (uint32_t)n);
+    k_powers<0><<<cdiv(lanes, 256), 256, 0, cx().stream>>>(args, cx().st_sc.as<uint32_t>(), (uint32_t)n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out, g_ctx.st_sc.p, n * 32, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(out, cx().st_sc.p, n * 32, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
@@ -1720,14 +1863,14 @@ int bpgpu_powers(int curve, const uint64_t f[4], uint64_t start, size_t n, uint6
 // ptr/idx: compressed rows of the product to run (already validated, 32-bit); perm: value index per entry or null
 static int spmv_run(int curve, const uint32_t* ptr, const uint32_t* idx, const uint32_t* perm, size_t nnz,
                     const uint64_t* vals, size_t n_out, const uint64_t* vec, size_t vec_len, uint64_t* out) {
-  DevBuf* B = g_ctx.aux;
+  DevBuf* B = cx().aux;
   TRY(B[0].ensure((n_out + 1) * 4));
   TRY(B[1].ensure(nnz * 4 + 4));
   if (perm) TRY(B[2].ensure(nnz * 4 + 4));
   TRY(B[3].ensure(nnz * 32 + 32));
   TRY(B[4].ensure(vec_len * 32 + 32));
   TRY(B[5].ensure(n_out * 32));
-  hipStream_t st = g_ctx.stream;
+  hipStream_t st = cx().stream;
   HIP_TRY(upload_async(B[0].p, ptr, (n_out + 1) * 4, st));
   if (nnz) {
     HIP_TRY(upload_async(B[1].p, idx, nnz * 4, st));
@@ -1766,7 +1909,7 @@ static int spmv_check(const uint64_t* row_ptr, const uint64_t* col_idx, const ui
 
 int bpgpu_mat_vec_mult(int curve, const uint64_t* row_ptr, const uint64_t* col_idx, const uint64_t* vals, size_t n_rows,
                        const uint64_t* vec, size_t vec_len, uint64_t* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   size_t nnz = 0;
@@ -1786,7 +1929,7 @@ int bpgpu_mat_vec_mult(int curve, const uint64_t* row_ptr, const uint64_t* col_i
 
 int bpgpu_vec_mat_mult(int curve, const uint64_t* vec, size_t vec_len, const uint64_t* row_ptr, const uint64_t* col_idx,
                        const uint64_t* vals, size_t n_rows, size_t output_size, uint64_t* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   size_t nnz = 0;
@@ -1845,7 +1988,7 @@ static void lift_root(LiftArgs* a) {
 }  // extern "C++"
 
 int bpgpu_curve_lift_x(int curve, const uint64_t* xs, const uint8_t* greatest, size_t m, uint64_t* ys, uint8_t* ok) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (m > 0x3fffffffu) return fail(BPGPU_E_ARG, "m too large");
@@ -1857,12 +2000,12 @@ int bpgpu_curve_lift_x(int curve, const uint64_t* xs, const uint8_t* greatest, s
     if (curve == BPGPU_PALLAS) lift_root<0>(&args[0]); else lift_root<1>(&args[1]);
     have[curve] = true;
   }
-  DevBuf* B = g_ctx.aux;
+  DevBuf* B = cx().aux;
   TRY(B[0].ensure(m * 32));
   TRY(B[1].ensure(m));
   TRY(B[2].ensure(m * 32));
   TRY(B[3].ensure(m));
-  hipStream_t st = g_ctx.stream;
+  hipStream_t st = cx().stream;
   HIP_TRY(upload_async(B[0].p, xs, m * 32, st));
   HIP_TRY(upload_async(B[1].p, greatest, m, st));
   if (curve == BPGPU_PALLAS)
@@ -1886,22 +2029,24 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
                             const void* d_a_gens, const void* d_b_gens, const void* d_ip_gen, const uint64_t* a,
                             const uint64_t* b, size_t n, bpgpu_ipa** out) {
   const bool from_device = d_ip_gen != nullptr;
-  if (n > (1u << 30)) return fail(BPGPU_E_ARG, "n too large");
   // zero_pad_to_two_power (util/mod.rs:137-144): next power of two, at least 1
   size_t np = pow2_at_least(n < 1 ? 1 : n);
   bpgpu_ipa* s = new bpgpu_ipa();
+  s->ctx = &cx();
+  s->failed = false;
   s->curve = curve;
   s->np = np;
   s->len = np;
   s->lr_done = false;
   s->d_pts = nullptr;
   s->d_sc = nullptr;
-  s->freeze_thresh = np < g_ctx.freeze_len ? np : g_ctx.freeze_len;
+  const size_t freeze_len = g_freeze_len.load();
+  s->freeze_thresh = np < freeze_len ? np : freeze_len;
   s->lazy = false;
-  s->lazy_off = !g_ctx.pair_fold || np < 4;
+  s->lazy_off = !g_pair_fold.load() || np < 4;
   s->freeze_cap = s->lazy_off ? s->freeze_thresh : np;  // pair folding freezes at any length
   s->frozen = false;
-  s->freeze_disabled = g_ctx.freeze_len == 0;
+  s->freeze_disabled = freeze_len == 0;
   s->n0 = 0;
   s->sc_scaled = 2 * np + 2 + 6 * s->freeze_cap;
   ipa_mu_reset(s);
@@ -1909,24 +2054,24 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
   s->pooled = false;
   auto cleanup = [&]() {
     if (s->pooled) {
-      g_ctx.ipa_pool_busy = false;
+      cx().ipa_pool_busy = false;
     } else {
       if (s->d_pts) (void)hipFree(s->d_pts);
       if (s->d_sc) (void)hipFree(s->d_sc);
     }
     delete s;
   };
-  if (!g_ctx.ipa_pool_busy) {
-    int prc = g_ctx.ipa_pts.ensure((2 * np + 1) * 64);
-    if (prc == 0) prc = g_ctx.ipa_sc.ensure(sc_words * 4);
+  if (!cx().ipa_pool_busy) {
+    int prc = cx().ipa_pts.ensure((2 * np + 1) * 64);
+    if (prc == 0) prc = cx().ipa_sc.ensure(sc_words * 4);
     if (prc != 0) {
       delete s;
       return prc;
     }
-    s->d_pts = g_ctx.ipa_pts.as<uint32_t>();
-    s->d_sc = g_ctx.ipa_sc.as<uint32_t>();
+    s->d_pts = cx().ipa_pts.as<uint32_t>();
+    s->d_sc = cx().ipa_sc.as<uint32_t>();
     s->pooled = true;
-    g_ctx.ipa_pool_busy = true;
+    cx().ipa_pool_busy = true;
   } else {  // a second session open at the same time owns its buffers
     hipError_t e = hipMalloc((void**)&s->d_pts, (2 * np + 1) * 64);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_sc, sc_words * 4);
@@ -1935,7 +2080,7 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
       return fail(BPGPU_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     }
   }
-  hipStream_t st = g_ctx.stream;
+  hipStream_t st = cx().stream;
   int rc = 0;
   do {
     // identity points / zero scalars are all-zero bytes in both device formats
@@ -1959,8 +2104,8 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
         break;
       }
     } else {
-      if ((rc = g_ctx.st_pts_in.ensure((2 * n + 1) * 96)) != 0) break;
-      uint8_t* stg = (uint8_t*)g_ctx.st_pts_in.p;
+      if ((rc = cx().st_pts_in.ensure((2 * n + 1) * 96)) != 0) break;
+      uint8_t* stg = (uint8_t*)cx().st_pts_in.p;
       if ((n && (upload_async(stg, a_gens_xyz, n * 96, st) != hipSuccess ||
                  upload_async(stg + n * 96, b_gens_xyz, n * 96, st) != hipSuccess)) ||
           upload_async(stg + 2 * n * 96, ip_gen_xyz, 96, st) != hipSuccess) {
@@ -1978,13 +2123,15 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
     cleanup();
     return rc;
   }
+  cx().open_sessions++;
   *out = s;
   return 0;
 }
 
 int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
                     const uint64_t* a, const uint64_t* b, size_t n, bpgpu_ipa** out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  if (n > BPGPU_IPA_MAX_N) return fail(BPGPU_E_ARG, "n = %zu: an IPA session holds at most 2^26 elements per vector", n);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (!out || !ip_gen_xyz) return fail(BPGPU_E_ARG, "null pointer");
@@ -1994,7 +2141,8 @@ int bpgpu_ipa_begin(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gen
 
 int bpgpu_ipa_begin_device(int curve, const void* d_a_gens, const void* d_b_gens, const void* d_ip_gen, const uint64_t* a,
                            const uint64_t* b, size_t n, bpgpu_ipa** out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  if (n > BPGPU_IPA_MAX_N) return fail(BPGPU_E_ARG, "n = %zu: an IPA session holds at most 2^26 elements per vector", n);
+  CtxLock lk;
   TRY(check_ready());
   TRY(check_curve(curve));
   if (!out || !d_ip_gen) return fail(BPGPU_E_ARG, "null pointer");
@@ -2002,18 +2150,46 @@ int bpgpu_ipa_begin_device(int curve, const void* d_a_gens, const void* d_b_gens
   return ipa_begin_common(curve, nullptr, nullptr, nullptr, d_a_gens, d_b_gens, d_ip_gen, a, b, n, out);
 }
 
-size_t bpgpu_ipa_len(const bpgpu_ipa* s) { return s ? s->len : 0; }
+size_t bpgpu_ipa_len(const bpgpu_ipa* s) {
+  if (!s) return 0;
+  std::lock_guard<std::mutex> lk(s->ctx->mu);
+  return s->len;
+}
+
+// A failure inside a round leaves a, b, the generators and the weights partly updated: the session is
+// marked failed and refuses every later call (a retry would fold the scalars twice).
+#define IPA_TRY(expr)       \
+  do {                      \
+    int r_ = (expr);        \
+    if (r_ != 0) {          \
+      s->failed = true;     \
+      return r_;            \
+    }                       \
+  } while (0)
+#define IPA_HIP_TRY(expr)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      s->failed = true;                                                                            \
+      return fail(BPGPU_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                              \
+  } while (0)
+static int ipa_usable(const bpgpu_ipa* s) {
+  if (s->failed) return fail(BPGPU_E_STATE, "the session failed in an earlier call; free it");
+  return 0;
+}
 
 int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9]) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  TRY(check_ready());
   if (!s || !l_xy_inf || !r_xy_inf) return fail(BPGPU_E_ARG, "null pointer");
+  CtxLock lk(s->ctx);
+  TRY(check_ready());
+  TRY(ipa_usable(s));
   if (s->len <= 1) return fail(BPGPU_E_STATE, "the vectors already have length 1");
   if (s->lr_done) return fail(BPGPU_E_STATE, "round_fold must follow round_lr");
   const uint32_t n = (uint32_t)(s->len / 2), np = (uint32_t)s->np;
   // c_L = <a[..n], b[n..]>, c_R = <a[n..], b[..n]>   (bp_iter.rs:73,80)
   IpPair pl{0u, np + n}, pr{n, np};
-  TRY(ip_launch(s->curve, s->d_sc, pl, pr, 2, n, s->d_sc + 8ull * (2 * np), s->d_sc + 8ull * (2 * np + 1)));
+  TRY(ip_launch(s->curve, s->d_sc, s->d_sc, pl, pr, 2, n, s->d_sc + 8ull * (2 * np), s->d_sc + 8ull * (2 * np + 1)));
   MsmPlan plan;
   memset(&plan, 0, sizeof plan);
   plan.M = 2;
@@ -2021,10 +2197,10 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
   if (s->frozen) {
     const uint32_t n0 = (uint32_t)s->n0, fs = 2 * np + 2;
     if (s->curve == BPGPU_PALLAS)
-      k_frozen_scalars<1><<<cdiv(n0, 256), 256, 0, g_ctx.stream>>>(s->d_sc, s->d_sc + 8ull * np, s->wA(), s->wB(), s->fsc(),
+      k_frozen_scalars<1><<<cdiv(n0, 256), 256, 0, cx().stream>>>(s->d_sc, s->d_sc + 8ull * np, s->wA(), s->wB(), s->fsc(),
                                                                 n0, n);
     else
-      k_frozen_scalars<0><<<cdiv(n0, 256), 256, 0, g_ctx.stream>>>(s->d_sc, s->d_sc + 8ull * np, s->wA(), s->wB(), s->fsc(),
+      k_frozen_scalars<0><<<cdiv(n0, 256), 256, 0, cx().stream>>>(s->d_sc, s->d_sc + 8ull * np, s->wA(), s->wB(), s->fsc(),
                                                                 n0, n);
     HIP_TRY(hipGetLastError());
     plan.n = 2 * n0 + 1;
@@ -2050,10 +2226,10 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
     FoldScalars m = make_fold_scalars(s->muA, s->muB);
     const uint32_t blocks = cdiv(2 * n, 256) < 2048 ? cdiv(2 * n, 256) : 2048;
     if (s->curve == BPGPU_PALLAS)
-      k_scale_scalars<1><<<dim3(blocks, 2), 256, 0, g_ctx.stream>>>(s->d_sc, s->d_sc + 8ull * sa, s->d_sc + 8ull * np,
+      k_scale_scalars<1><<<dim3(blocks, 2), 256, 0, cx().stream>>>(s->d_sc, s->d_sc + 8ull * sa, s->d_sc + 8ull * np,
                                                                    s->d_sc + 8ull * sb, m, 2 * n);
     else
-      k_scale_scalars<0><<<dim3(blocks, 2), 256, 0, g_ctx.stream>>>(s->d_sc, s->d_sc + 8ull * sa, s->d_sc + 8ull * np,
+      k_scale_scalars<0><<<dim3(blocks, 2), 256, 0, cx().stream>>>(s->d_sc, s->d_sc + 8ull * sa, s->d_sc + 8ull * np,
                                                                    s->d_sc + 8ull * sb, m, 2 * n);
     HIP_TRY(hipGetLastError());
   }
@@ -2073,78 +2249,81 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
 }
 
 int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  TRY(check_ready());
   if (!s || !x || !x_inv) return fail(BPGPU_E_ARG, "null pointer");
+  CtxLock lk(s->ctx);
+  TRY(check_ready());
+  TRY(ipa_usable(s));
   if (!s->lr_done) return fail(BPGPU_E_STATE, "round_lr must precede round_fold");
   const uint32_t n = (uint32_t)(s->len / 2), np = (uint32_t)s->np;
   // a' = x a_lo + x^-1 a_hi;  b' = x^-1 b_lo + x b_hi          (bp_iter.rs:88-95)
   FoldScalars fa = make_fold_scalars(x, x_inv), fb = make_fold_scalars(x_inv, x);
   uint32_t* da = s->d_sc;
   uint32_t* db = s->d_sc + 8ull * np;
-  TRY(fold_scalars_launch(s->curve, da, da, fa, db, db, fb, 2, n));
+  IPA_TRY(fold_scalars_launch(s->curve, da, da, fa, db, db, fb, 2, n));
   // A' = x^-1 A_lo + x A_hi;  B' = x B_lo + x^-1 B_hi          (bp_iter.rs:97-104)
   // pair folding: a long round whose successor is long too leaves its generators alone; the next
   // round's L, R run over them with weighted scalars and its fold applies both challenges at once
   if (!s->frozen && !s->lazy_off && s->len >= 4 && s->len / 4 >= (s->freeze_thresh > 1 ? s->freeze_thresh : 1) &&
       (s->curve == BPGPU_PALLAS ? are_inverses<1>(x, x_inv) : are_inverses<0>(x, x_inv))) {
-    TRY(ipa_freeze(s));
+    IPA_TRY(ipa_freeze(s));
     s->lazy = true;
   }
   if (s->frozen) {
     // deferred: the fold only updates the weights of the frozen generators
     const uint32_t n0 = (uint32_t)s->n0;
     if (s->curve == BPGPU_PALLAS)
-      k_frozen_update<1><<<cdiv(n0, 256), 256, 0, g_ctx.stream>>>(s->wA(), s->wB(), n0, n, fa);
+      k_frozen_update<1><<<cdiv(n0, 256), 256, 0, cx().stream>>>(s->wA(), s->wB(), n0, n, fa);
     else
-      k_frozen_update<0><<<cdiv(n0, 256), 256, 0, g_ctx.stream>>>(s->wA(), s->wB(), n0, n, fa);
-    HIP_TRY(hipGetLastError());
+      k_frozen_update<0><<<cdiv(n0, 256), 256, 0, cx().stream>>>(s->wA(), s->wB(), n0, n, fa);
+    IPA_HIP_TRY(hipGetLastError());
     std::array<uint64_t, 8> ch;
     memcpy(ch.data(), x, 32);
     memcpy(ch.data() + 4, x_inv, 32);
     s->pending.push_back(ch);
-    if (s->lazy && s->pending.size() == 2) TRY(ipa_pair_fold(s));
+    if (s->lazy && s->pending.size() == 2) IPA_TRY(ipa_pair_fold(s));
   } else {
-    TRY(ipa_fold_generators(s, x, x_inv, n));
+    IPA_TRY(ipa_fold_generators(s, x, x_inv, n));
   }
   s->len = n;
   s->lr_done = false;
-  if (!s->frozen && !s->freeze_disabled && n > 1 && n <= s->freeze_thresh) TRY(ipa_freeze(s));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  if (!s->frozen && !s->freeze_disabled && n > 1 && n <= s->freeze_thresh) IPA_TRY(ipa_freeze(s));
+  IPA_HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_ipa_finish(bpgpu_ipa* s, uint64_t final_a[4], uint64_t final_b[4]) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  TRY(check_ready());
   if (!s || !final_a || !final_b) return fail(BPGPU_E_ARG, "null pointer");
+  CtxLock lk(s->ctx);
+  TRY(check_ready());
+  TRY(ipa_usable(s));
   if (s->len != 1 || s->lr_done) return fail(BPGPU_E_STATE, "the loop has not finished");
-  HIP_TRY(hipMemcpyAsync(final_a, s->d_sc, 32, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipMemcpyAsync(final_b, s->d_sc + 8ull * s->np, 32, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(final_a, s->d_sc, 32, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipMemcpyAsync(final_b, s->d_sc + 8ull * s->np, 32, hipMemcpyDeviceToHost, cx().stream));
+  HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 
 int bpgpu_ipa_export(bpgpu_ipa* s, uint64_t* a_gens_xyz, uint64_t* b_gens_xyz, uint64_t* a, uint64_t* b) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  TRY(check_ready());
   if (!s) return fail(BPGPU_E_ARG, "null session");
+  CtxLock lk(s->ctx);
+  TRY(check_ready());
+  TRY(ipa_usable(s));
   if (s->lr_done) return fail(BPGPU_E_STATE, "export between round_lr and round_fold");
   if (a_gens_xyz || b_gens_xyz) {
     TRY(ipa_materialise(s));
     TRY(ipa_normalise(s));
   }
   const size_t n = s->len, np = s->np;
-  hipStream_t st = g_ctx.stream;
-  TRY(g_ctx.st_out.ensure(n * 96));
+  hipStream_t st = cx().stream;
+  TRY(cx().st_out.ensure(n * 96));
   if (a_gens_xyz) {
-    TRY(points_out(s->curve, s->d_pts, g_ctx.st_out.as<uint32_t>(), n));
-    HIP_TRY(hipMemcpyAsync(a_gens_xyz, g_ctx.st_out.p, n * 96, hipMemcpyDeviceToHost, st));
+    TRY(points_out(s->curve, s->d_pts, cx().st_out.as<uint32_t>(), n));
+    HIP_TRY(hipMemcpyAsync(a_gens_xyz, cx().st_out.p, n * 96, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
   }
   if (b_gens_xyz) {
-    TRY(points_out(s->curve, s->d_pts + 16ull * np, g_ctx.st_out.as<uint32_t>(), n));
-    HIP_TRY(hipMemcpyAsync(b_gens_xyz, g_ctx.st_out.p, n * 96, hipMemcpyDeviceToHost, st));
+    TRY(points_out(s->curve, s->d_pts + 16ull * np, cx().st_out.as<uint32_t>(), n));
+    HIP_TRY(hipMemcpyAsync(b_gens_xyz, cx().st_out.p, n * 96, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
   }
   if (a) HIP_TRY(hipMemcpyAsync(a, s->d_sc, n * 32, hipMemcpyDeviceToHost, st));
@@ -2155,15 +2334,197 @@ int bpgpu_ipa_export(bpgpu_ipa* s, uint64_t* a_gens_xyz, uint64_t* b_gens_xyz, u
 
 void bpgpu_ipa_free(bpgpu_ipa* s) {
   if (!s) return;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_ctx.ready) (void)hipStreamSynchronize(g_ctx.stream);
+  CtxLock lk(s->ctx);
+  if (cx().ready) {
+    (void)hipSetDevice(cx().device);
+    (void)hipStreamSynchronize(cx().stream);
+  }
+  cx().open_sessions--;
   if (s->pooled) {
-    g_ctx.ipa_pool_busy = false;
+    cx().ipa_pool_busy = false;
   } else {
     if (s->d_pts) (void)hipFree(s->d_pts);
     if (s->d_sc) (void)hipFree(s->d_sc);
   }
   delete s;
+}
+
+// ---- sharded (multi-GPU) MSM, one process ------------------------------------------------------
+// pippenger_msm (src/util/msm.rs:88-92) is called from ONE process; to use the 8 GPUs of a node from that
+// process the library keeps one context per GPU and cuts the pairs into contiguous ranges
+// [g n / P, (g+1) n / P).  One persistent host thread per context runs the single-GPU pipeline on
+// its range; every context ends with its own Horner tail on the host, so the per-GPU partial (72 bytes) is
+// already in host memory when the leg ends and the combine is P - 1 host additions (bpgpu_points_sum's
+// loop).  A device-side gather (RCCL) would upload those 72 bytes again to move them between GPUs and bring
+// them back: the in-process path does not use it; the one-process-per-GPU path (bench.py, sharded.py) does,
+// through torch.distributed, because there the partials live in different address spaces.
+extern "C++" {
+namespace {
+struct ShardJob {
+  int rc = 0;
+  std::string err;
+};
+// runs f(g) with shard g's context current and locked on worker g; first failure wins
+int run_on_shards(const std::function<int(int)>& f) {
+  const int P = (int)g_shards.size();
+  std::vector<ShardJob> jobs(P);
+  g_shard_pool.run([&](int g) {
+    CtxLock lk(g_shards[g].get());
+    int rc = check_ready();
+    if (rc == 0) rc = f(g);
+    jobs[g].rc = rc;
+    if (rc) jobs[g].err = g_err;
+  });
+  for (int g = 0; g < P; g++)
+    if (jobs[g].rc) return fail(jobs[g].rc, "shard %d: %s", g, jobs[g].err.c_str());
+  return 0;
+}
+int sum_partials(int curve, const std::vector<std::array<uint64_t, 9>>& parts, uint64_t out[9]) {
+  return bpgpu_points_sum(curve, parts.empty() ? nullptr : parts[0].data(), parts.size(), out);
+}
+}  // namespace
+}  // extern "C++"
+
+struct bpgpu_sharded_gens {
+  int curve;
+  size_t n;
+  std::vector<void*> d_pts;  // per shard: its range as dev affine points
+  std::vector<size_t> lo, cnt;
+};
+
+int bpgpu_sharded_init(int n_ctx, const int* devices) {
+  std::lock_guard<std::mutex> reg(g_reg_mu);
+  if (n_ctx < 1 || n_ctx > 64) return fail(BPGPU_E_ARG, "n_ctx = %d outside [1, 64]", n_ctx);
+  if (!g_shards.empty()) {
+    bool same = (int)g_shards.size() == n_ctx;
+    for (int g = 0; same && g < n_ctx; g++) same = g_shards[g]->device == (devices ? devices[g] : g);
+    if (same) return 0;
+    return fail(BPGPU_E_STATE, "the sharded contexts are already initialised with another device list");
+  }
+  std::vector<std::unique_ptr<Ctx>> made;
+  for (int g = 0; g < n_ctx; g++) {
+    made.emplace_back(new Ctx());
+    int rc = ctx_init(*made.back(), devices ? devices[g] : g);
+    if (rc) {
+      for (auto& c : made) ctx_release(*c);
+      return rc;
+    }
+  }
+  g_shards = std::move(made);
+  g_shard_pool.start(n_ctx);
+  return 0;
+}
+
+int bpgpu_sharded_count(void) {
+  std::lock_guard<std::mutex> reg(g_reg_mu);
+  return (int)g_shards.size();
+}
+
+static int msm_sharded_host(int curve, const uint64_t* points, int fmt, const uint64_t* scalars, size_t n,
+                            uint64_t out_xy_inf[9]) {
+  std::lock_guard<std::mutex> reg(g_reg_mu);
+  if (g_shards.empty()) return fail(BPGPU_E_NOINIT, "bpgpu_sharded_init has not been called");
+  TRY(check_curve(curve));
+  if (!out_xy_inf) return fail(BPGPU_E_ARG, "null output");
+  if (n && (!points || !scalars)) return fail(BPGPU_E_ARG, "null pointer");
+  const size_t P = g_shards.size();
+  if ((n + P - 1) / P > BPGPU_MSM_MAX_N) return fail(BPGPU_E_ARG, "n = %zu: more than 2^28 points per shard", n);
+  std::vector<std::array<uint64_t, 9>> parts(P);
+  const size_t pw = fmt == 0 ? 12 : 8;
+  TRY(run_on_shards([&](int g) {
+    const size_t lo = (size_t)g * n / P, hi = (size_t)(g + 1) * n / P, cnt = hi - lo;
+    Ctx& C = cx();
+    if (cnt) {
+      TRY(C.st_pts_in.ensure(cnt * pw * 8));
+      TRY(C.st_pts.ensure(cnt * 64));
+      TRY(C.st_sc.ensure(cnt * 32));
+      HIP_TRY(upload_async(C.st_pts_in.p, points + lo * pw, cnt * pw * 8, C.stream));
+      HIP_TRY(upload_async(C.st_sc.p, scalars + lo * 4, cnt * 32, C.stream));
+      TRY(points_in(curve, C.st_pts_in.as<uint32_t>(), C.st_pts.as<uint32_t>(), cnt, fmt));
+    }
+    return msm_dispatch(curve, C.st_pts.as<uint32_t>(), C.st_sc.as<uint32_t>(), single_plan((uint32_t)cnt),
+                        (uint64_t(*)[9])parts[g].data());
+  }));
+  return sum_partials(curve, parts, out_xy_inf);
+}
+
+int bpgpu_msm_sharded(int curve, const uint64_t* points_xyz, const uint64_t* scalars, size_t n, uint64_t out_xy_inf[9]) {
+  return msm_sharded_host(curve, points_xyz, 0, scalars, n, out_xy_inf);
+}
+int bpgpu_msm_sharded_affine(int curve, const uint64_t* points_xy, const uint64_t* scalars, size_t n,
+                             uint64_t out_xy_inf[9]) {
+  return msm_sharded_host(curve, points_xy, 1, scalars, n, out_xy_inf);
+}
+
+int bpgpu_sharded_gens_load(int curve, const uint64_t* points, size_t n, int fmt, bpgpu_sharded_gens** out) {
+  std::lock_guard<std::mutex> reg(g_reg_mu);
+  if (g_shards.empty()) return fail(BPGPU_E_NOINIT, "bpgpu_sharded_init has not been called");
+  TRY(check_curve(curve));
+  if (!out || (n && !points)) return fail(BPGPU_E_ARG, "null pointer");
+  if (fmt != 0 && fmt != 1) return fail(BPGPU_E_ARG, "fmt must be 0 (jacobian) or 1 (affine)");
+  const size_t P = g_shards.size();
+  if ((n + P - 1) / P > BPGPU_MSM_MAX_N) return fail(BPGPU_E_ARG, "n = %zu: more than 2^28 points per shard", n);
+  bpgpu_sharded_gens* h = new bpgpu_sharded_gens();
+  h->curve = curve;
+  h->n = n;
+  h->d_pts.assign(P, nullptr);
+  h->lo.resize(P);
+  h->cnt.resize(P);
+  const size_t pw = fmt == 0 ? 12 : 8;
+  int rc = run_on_shards([&](int g) {
+    const size_t lo = (size_t)g * n / P, hi = (size_t)(g + 1) * n / P, cnt = hi - lo;
+    h->lo[g] = lo;
+    h->cnt[g] = cnt;
+    Ctx& C = cx();
+    HIP_TRY(hipMalloc(&h->d_pts[g], (cnt ? cnt : 1) * 64));
+    if (cnt) {
+      TRY(C.st_pts_in.ensure(cnt * pw * 8));
+      HIP_TRY(upload_async(C.st_pts_in.p, points + lo * pw, cnt * pw * 8, C.stream));
+      TRY(points_in(curve, C.st_pts_in.as<uint32_t>(), (uint32_t*)h->d_pts[g], cnt, fmt));
+      HIP_TRY(hipStreamSynchronize(C.stream));
+    }
+    return 0;
+  });
+  if (rc) {
+    (void)run_on_shards([&](int g) {
+      if (h->d_pts[g]) (void)hipFree(h->d_pts[g]);
+      return 0;
+    });
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+int bpgpu_sharded_gens_msm(bpgpu_sharded_gens* h, const uint64_t* scalars, uint64_t out_xy_inf[9]) {
+  std::lock_guard<std::mutex> reg(g_reg_mu);
+  if (!h || !out_xy_inf || (h->n && !scalars)) return fail(BPGPU_E_ARG, "null pointer");
+  if (g_shards.size() != h->d_pts.size()) return fail(BPGPU_E_STATE, "the sharded contexts changed since the generators were loaded");
+  std::vector<std::array<uint64_t, 9>> parts(g_shards.size());
+  TRY(run_on_shards([&](int g) {
+    Ctx& C = cx();
+    const size_t cnt = h->cnt[g];
+    if (cnt) {
+      TRY(C.st_sc.ensure(cnt * 32));
+      HIP_TRY(upload_async(C.st_sc.p, scalars + h->lo[g] * 4, cnt * 32, C.stream));
+    }
+    return msm_dispatch(h->curve, (const uint32_t*)h->d_pts[g], C.st_sc.as<uint32_t>(), single_plan((uint32_t)cnt),
+                        (uint64_t(*)[9])parts[g].data());
+  }));
+  return sum_partials(h->curve, parts, out_xy_inf);
+}
+
+void bpgpu_sharded_gens_free(bpgpu_sharded_gens* h) {
+  if (!h) return;
+  std::lock_guard<std::mutex> reg(g_reg_mu);
+  if (g_shards.size() == h->d_pts.size())
+    (void)run_on_shards([&](int g) {
+      (void)hipStreamSynchronize(cx().stream);
+      if (h->d_pts[g]) (void)hipFree(h->d_pts[g]);
+      return 0;
+    });
+  delete h;
 }
 
 // ---- sharded-MSM helper -----------------------------------------------------
@@ -2194,44 +2555,53 @@ int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t o
 // ---- instrumentation ----------------------------------------------------------
 int bpgpu_last_msm_timings(float out_ms[8]) {
   if (!out_ms) return fail(BPGPU_E_ARG, "null pointer");
-  memcpy(out_ms, g_ctx.msm_ms, sizeof g_ctx.msm_ms);
+  CtxLock lk;
+  memcpy(out_ms, cx().msm_ms, sizeof cx().msm_ms);
   return 0;
 }
 
 int bpgpu_last_msm_entries(uint64_t* entries) {
   if (!entries) return fail(BPGPU_E_ARG, "null pointer");
-  *entries = g_ctx.msm_entries;
+  CtxLock lk;
+  *entries = cx().msm_entries;
+  return 0;
+}
+
+int bpgpu_last_fold_ops(uint64_t out[4]) {
+  if (!out) return fail(BPGPU_E_ARG, "null pointer");
+  CtxLock lk;
+  memcpy(out, cx().fold_ops, sizeof cx().fold_ops);
   return 0;
 }
 
 int bpgpu_last_op_ms(float* ms) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   if (!ms) return fail(BPGPU_E_ARG, "null pointer");
-  HIP_TRY(hipEventSynchronize(g_ctx.op_ev[1]));
-  HIP_TRY(hipEventElapsedTime(ms, g_ctx.op_ev[0], g_ctx.op_ev[1]));
+  HIP_TRY(hipEventSynchronize(cx().op_ev[1]));
+  HIP_TRY(hipEventElapsedTime(ms, cx().op_ev[0], cx().op_ev[1]));
   return 0;
 }
 
 int bpgpu_measure_mad_peak(double* mads_per_sec) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLock lk;
   TRY(check_ready());
   if (!mads_per_sec) return fail(BPGPU_E_ARG, "null pointer");
-  TRY(g_ctx.st_out.ensure(4096));
+  TRY(cx().st_out.ensure(4096));
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, g_ctx.device));
+  HIP_TRY(hipGetDeviceProperties(&prop, cx().device));
   const int iters = 8192, grid = prop.multiProcessorCount * 8;
-  hipStream_t st = g_ctx.stream;
-  k_mad_peak<<<grid, 256, 0, st>>>(g_ctx.st_out.as<uint32_t>(), 1u, iters);
+  hipStream_t st = cx().stream;
+  k_mad_peak<<<grid, 256, 0, st>>>(cx().st_out.as<uint32_t>(), 1u, iters);
   HIP_TRY(hipStreamSynchronize(st));
   float best = 1e30f;
   for (int r = 0; r < 5; r++) {
-    HIP_TRY(hipEventRecord(g_ctx.ev[6], st));
-    k_mad_peak<<<grid, 256, 0, st>>>(g_ctx.st_out.as<uint32_t>(), (uint32_t)r + 2u, iters);
-    HIP_TRY(hipEventRecord(g_ctx.ev[7], st));
-    HIP_TRY(hipEventSynchronize(g_ctx.ev[7]));
+    HIP_TRY(hipEventRecord(cx().ev[6], st));
+    k_mad_peak<<<grid, 256, 0, st>>>(cx().st_out.as<uint32_t>(), (uint32_t)r + 2u, iters);
+    HIP_TRY(hipEventRecord(cx().ev[7], st));
+    HIP_TRY(hipEventSynchronize(cx().ev[7]));
     float ms;
-    HIP_TRY(hipEventElapsedTime(&ms, g_ctx.ev[6], g_ctx.ev[7]));
+    HIP_TRY(hipEventElapsedTime(&ms, cx().ev[6], cx().ev[7]));
     if (ms < best) best = ms;
   }
   *mads_per_sec = (double)grid * 256.0 * iters * 32.0 / (best * 1e-3);

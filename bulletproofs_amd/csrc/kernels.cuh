@@ -770,20 +770,20 @@ __device__ __forceinline__ Fe fe_partial_reduce(const Fe& a) {
 }
 
 struct IpPair {
-  uint32_t a_off, b_off;  // element offsets into the scalar array
+  uint32_t a_off, b_off;  // element offsets of a into sa and of b into sb
 };
 
 // partial[blockIdx.y][blockIdx.x] = sum over this block's slice of a[i]*b[i] (device form of the
 // *ark-form product*, see k_ip_final).  Up to two inner products per launch (the round's
 // <a_lo,b_hi> and <a_hi,b_lo>, bp_iter.rs:73,80).
 template <int SF>
-__global__ void __launch_bounds__(256) k_ip_partial(const uint32_t* __restrict__ sc, IpPair p0, IpPair p1, uint32_t n,
-                                                    uint32_t* __restrict__ partial) {
+__global__ void __launch_bounds__(256) k_ip_partial(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ sb, IpPair p0,
+                                                    IpPair p1, uint32_t n, uint32_t* __restrict__ partial) {
   using F = Fp<SF>;
   __shared__ int32_t sh[256 * 9];
   IpPair pr = blockIdx.y == 0 ? p0 : p1;
-  const uint32_t* a = sc + 8ull * pr.a_off;
-  const uint32_t* b = sc + 8ull * pr.b_off;
+  const uint32_t* a = sa + 8ull * pr.a_off;
+  const uint32_t* b = sb + 8ull * pr.b_off;
   uint32_t tid = threadIdx.x;
   Fe acc = F::zero();
   for (uint32_t i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
@@ -990,6 +990,13 @@ __global__ void __launch_bounds__(256) k_frozen_scalars(const uint32_t* __restri
 // 4-bit codes, position 0 = least significant:  code & 7: 0 none, 1 first base, 2 second base,
 // 3 first + second, 4 first - second;  code & 8: negate.
 // ---------------------------------------------------------------------------
+// The recoded multipliers of a fold launch travel as kernel arguments (two plans, one per generator
+// vector: at most 440 bytes), so a launch needs neither a device buffer nor a synchronisation.
+template <class T>
+struct Plans2 {
+  T p[2];
+};
+
 struct FoldPlan {
   uint32_t codes_p[17];  // pair (P, phi P), up to 136 positions, 8 per word
   uint32_t codes_q[17];  // pair (Q, phi Q)
@@ -1028,7 +1035,7 @@ __device__ __forceinline__ void affine_sum_diff(const Aff& a, const Aff& b, cons
 template <int BF>
 __global__ void __launch_bounds__(256) k_fold_points(const uint32_t* __restrict__ g0, uint32_t* __restrict__ o0,
                                                      const uint32_t* __restrict__ g1, uint32_t* __restrict__ o1,
-                                                     const FoldPlan* __restrict__ plans, uint32_t n) {
+                                                     const Plans2<FoldPlan> plans, uint32_t n) {
   using F = Fp<BF>;
   using E = Ec<BF>;
   using IO = PointIo<BF>;
@@ -1036,7 +1043,7 @@ __global__ void __launch_bounds__(256) k_fold_points(const uint32_t* __restrict_
   if (i >= n) return;
   const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
-  const FoldPlan* f = plans + blockIdx.y;
+  const FoldPlan* f = &plans.p[blockIdx.y];
   Aff P = IO::load_dev_affine(g + 16ull * i);
   Aff Q = IO::load_dev_affine(g + 16ull * (i + n));
   Xyzz acc;
@@ -1148,7 +1155,7 @@ __device__ __forceinline__ Fe block_inverse_256(const Fe& v, uint32_t (*tree)[9]
 template <int BF>
 __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const uint32_t* q0, uint32_t* o0,
                                                     const uint32_t* p1, const uint32_t* q1, uint32_t* o1,
-                                                    const MonicPlan* __restrict__ plans, uint32_t n, int has_p) {
+                                                    const Plans2<MonicPlan> plans, uint32_t n, int has_p) {
   using F = Fp<BF>;
   using E = Ec<BF>;
   using IO = PointIo<BF>;
@@ -1158,7 +1165,7 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
   const uint32_t* gp = blockIdx.y == 0 ? p0 : p1;
   const uint32_t* gq = blockIdx.y == 0 ? q0 : q1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
-  const MonicPlan* f = plans + blockIdx.y;
+  const MonicPlan* f = &plans.p[blockIdx.y];
   Xyzz acc = E::identity();
   if (active) {
     Aff Q = IO::load_dev_affine(gq + 16ull * i);
@@ -1213,7 +1220,7 @@ struct Joint4Plan {
 };
 template <int BF>
 __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_t* o0, const uint32_t* g1, uint32_t* o1,
-                                                     const Joint4Plan* __restrict__ plans, uint32_t q) {
+                                                     const Plans2<Joint4Plan> plans, uint32_t q) {
   using F = Fp<BF>;
   using E = Ec<BF>;
   using IO = PointIo<BF>;
@@ -1222,7 +1229,7 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
   const bool active = i < q;
   const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
-  const Joint4Plan* f = plans + blockIdx.y;
+  const Joint4Plan* f = &plans.p[blockIdx.y];
   Xyzz acc = E::identity();
   if (active) {
     const Aff Q0 = IO::load_dev_affine(g + 16ull * (i + q));

@@ -63,9 +63,17 @@ SIGNATURES = {
     "bpgpu_ipa_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bpgpu_ipa_free": (None, [c_void_p]),
     "bpgpu_points_sum": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_sharded_init": (c_int, [c_int, c_void_p]),
+    "bpgpu_sharded_count": (c_int, []),
+    "bpgpu_msm_sharded": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_msm_sharded_affine": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_sharded_gens_load": (c_int, [c_int, c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
+    "bpgpu_sharded_gens_msm": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "bpgpu_sharded_gens_free": (None, [c_void_p]),
     "bpgpu_last_msm_timings": (c_int, [POINTER(c_float)]),
     "bpgpu_last_msm_entries": (c_int, [POINTER(c_uint64)]),
     "bpgpu_last_op_ms": (c_int, [POINTER(c_float)]),
+    "bpgpu_last_fold_ops": (c_int, [POINTER(c_uint64)]),
     "bpgpu_measure_mad_peak": (c_int, [POINTER(c_double)]),
 }
 
@@ -343,6 +351,61 @@ def ip_device(curve, d_a, d_b, n):
     return out
 
 
+def sharded_init(devices):
+    """One context per entry of `devices` (HIP device numbers; repeats allowed: rehearsal on one GPU)."""
+    d = np.ascontiguousarray(devices, dtype=np.int32)
+    _check(load().bpgpu_sharded_init(len(d), _ptr(d)))
+
+
+def sharded_count():
+    return load().bpgpu_sharded_count()
+
+
+def msm_sharded(curve, points_xyz, scalars):
+    """bpgpu_msm over the contexts of sharded_init: contiguous ranges, one per context, summed on the host."""
+    p, s = _u64(points_xyz, 12), _u64(scalars, 4)
+    n = min(len(p), len(s))
+    out = np.zeros(9, dtype=np.uint64)
+    _check(load().bpgpu_msm_sharded(curve, _ptr(p), _ptr(s), n, _ptr(out)))
+    return out
+
+
+def msm_sharded_affine(curve, points_xy, scalars):
+    p, s = _u64(points_xy, 8), _u64(scalars, 4)
+    n = min(len(p), len(s))
+    out = np.zeros(9, dtype=np.uint64)
+    _check(load().bpgpu_msm_sharded_affine(curve, _ptr(p), _ptr(s), n, _ptr(out)))
+    return out
+
+
+class ShardedGens:
+    """Generators resident on every context of sharded_init (each holds its contiguous range)."""
+
+    def __init__(self, curve, points, fmt=0):
+        p = _u64(points, 12 if fmt == 0 else 8)
+        h = c_void_p()
+        _check(load().bpgpu_sharded_gens_load(curve, _ptr(p), len(p), fmt, ctypes.byref(h)))
+        self.h, self.n = h.value, len(p)
+
+    def msm(self, scalars):
+        s = _u64(scalars, 4)
+        assert len(s) == self.n
+        out = np.zeros(9, dtype=np.uint64)
+        _check(load().bpgpu_sharded_gens_msm(self.h, _ptr(s), _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            load().bpgpu_sharded_gens_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def fold_scalars_device(curve, d_v, n_out, s_lo, s_hi, d_out=None):
     d_out = d_out or d_v
     _check(load().bpgpu_fold_scalars_device(curve, d_v.ptr, n_out, _ptr(_u64(s_lo)), _ptr(_u64(s_hi)), d_out.ptr))
@@ -381,6 +444,13 @@ def last_op_ms():
     v = c_float()
     _check(load().bpgpu_last_op_ms(ctypes.byref(v)))
     return v.value
+
+
+def last_fold_ops():
+    """(outputs, doublings, mixed additions, kernel kind) of the last generator-fold launch."""
+    out = (c_uint64 * 4)()
+    _check(load().bpgpu_last_fold_ops(out))
+    return [int(v) for v in out]
 
 
 def measure_mad_peak():

@@ -19,8 +19,10 @@
  * Results are group elements in *normalised* (affine) form: the shim rebuilds
  * Projective { x, y, z: 1 } (or zero()), see SURVEY.md section 0.3.
  *
- * Threading: callable from any host thread; calls on one device are serialised
- * by an internal mutex (the reference never calls msm concurrently).
+ * Threading: callable from any host thread; calls on one context (one per device: the
+ * primary one of bpgpu_init, one per entry of bpgpu_sharded_init) are serialised by that
+ * context's mutex (the reference never calls msm concurrently).  An IPA session runs on the
+ * context it was opened on.
  * Ownership: the caller owns every buffer it passes; the library copies.
  */
 #ifndef BPGPU_H
@@ -42,12 +44,21 @@ extern "C" {
 #define BPGPU_PALLAS 0
 #define BPGPU_VESTA 1
 
-/* Create (or reuse) the context on HIP device `device` and make it current for the
- * process.  Idempotent.  Replaces nothing in the reference (it has no device). */
+/* Size limits (the bucket sort keeps entry positions in 32 bits; 13 windows x 2^28 points < 2^32).  Larger
+ * inputs are rejected with BPGPU_E_ARG before any device work; split them and add the partial results
+ * (bpgpu_points_sum), or use bpgpu_msm_sharded. */
+#define BPGPU_MSM_MAX_N ((size_t)1 << 28) /* points per bpgpu_msm* call (and per shard of a sharded MSM) */
+#define BPGPU_IPA_MAX_N ((size_t)1 << 26) /* elements per vector of an IPA session */
+
+/* Create (or reuse) the primary context on HIP device `device`: the one every single-device entry point
+ * below runs on.  Idempotent.  Replaces nothing in the reference (it has no device).
+ * bpgpu_shutdown releases every context; it is refused (nothing is released, bpgpu_last_error says why)
+ * while an IPA session is still open, because the session's device memory belongs to its context. */
 int bpgpu_init(int device);
 void bpgpu_shutdown(void);
 const char* bpgpu_last_error(void);
-/* MSM window width override for tuning (0 = automatic).  */
+/* The three tuning knobs below are PROCESS-WIDE (every context, every thread): results never depend on
+ * them, timings do.  MSM window width override (0 = automatic).  */
 int bpgpu_set_window_bits(int c);
 /* IPA sessions whose vectors are at most this long defer the generator fold ("deferred
  * folding"; default 2^15, 0 = always fold).  Tuning only: results are identical either way. */
@@ -219,15 +230,37 @@ int bpgpu_ipa_verify_msm_device(int curve, const void* d_a_gens, const void* d_b
                                 const uint64_t* challenges, const uint64_t final_a[4],
                                 const uint64_t final_b[4], uint64_t out_xy_inf[9]);
 
-/* ---- helpers for the sharded (multi-GPU) MSM ---------------------------------
- * Each rank runs bpgpu_msm* on its contiguous point range; the per-rank results
- * (72 B each) are gathered (RCCL all_gather, done by the host language) and summed
- * here.  No reference counterpart (the reference is single-process). */
+/* ---- sharded (multi-GPU) MSM -------------------------------------------------
+ * `pippenger_msm` (reference src/util/msm.rs:88-92; call sites src/proofs/bp_iter.rs:68-81) runs in ONE
+ * process.  For that process to use several GPUs the library keeps one context per entry of `devices`
+ * (HIP device numbers; NULL = 0 .. n_ctx-1; a number may repeat -- several contexts on one GPU -- which is
+ * how the path is rehearsed on a one-GPU machine).  bpgpu_msm_sharded cuts the zipped pairs into contiguous
+ * ranges [g n / P, (g+1) n / P), runs the single-GPU pipeline on every range at once (one persistent host
+ * thread per context) and adds the P partial results on the host: each context's result is produced in host
+ * memory (72 B), so no device-side collective is involved in the one-process form.  Same argument meaning,
+ * edge cases and result as bpgpu_msm.  Independent of bpgpu_init (the single-device entry points keep using
+ * the primary context). */
+int bpgpu_sharded_init(int n_ctx, const int* devices);
+int bpgpu_sharded_count(void);
+int bpgpu_msm_sharded(int curve, const uint64_t* points_xyz, const uint64_t* scalars, size_t n,
+                      uint64_t out_xy_inf[9]);
+int bpgpu_msm_sharded_affine(int curve, const uint64_t* points_xy, const uint64_t* scalars, size_t n,
+                             uint64_t out_xy_inf[9]);
+/* Generators resident across calls (the IPA generators are fixed public parameters, src/relations/ipa.rs:28-36):
+ * load once -- every context keeps its range in HBM as dev affine points -- then one call per scalar vector
+ * (n scalars in host memory; each context uploads its range).  fmt: 0 = jacobian 96 B, 1 = affine 64 B. */
+typedef struct bpgpu_sharded_gens bpgpu_sharded_gens;
+int bpgpu_sharded_gens_load(int curve, const uint64_t* points, size_t n, int fmt, bpgpu_sharded_gens** out);
+int bpgpu_sharded_gens_msm(bpgpu_sharded_gens* g, const uint64_t* scalars, uint64_t out_xy_inf[9]);
+void bpgpu_sharded_gens_free(bpgpu_sharded_gens* g);
+/* One process per GPU instead (bench.py, bulletproofs_amd/sharded.py): each rank runs bpgpu_msm* on its
+ * range, the per-rank results (72 B each) are gathered (RCCL all_gather, done by the host language) and
+ * summed here.  Host-only; no reference counterpart (the reference is single-process). */
 int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t out_xy_inf[9]);
 
 /* ---- instrumentation ----------------------------------------------------------
- * Duration in milliseconds of the GPU phases of the last bpgpu_msm* call on this
- * thread's context, measured with HIP events on the library's stream:
+ * Duration in milliseconds of the GPU phases of the last bpgpu_msm* call on the primary
+ * context (whichever thread made it), measured with HIP events on the library's stream:
  * [0] digits + coarse histogram, [1] bin scan + scatter to bins, [2] sort inside bins,
  * [3] bucket accumulation (k_accum + k_heavy_merge), [4] unused, [5] bucket reduction,
  * [6] host tail (wall), [7] total GPU. */
@@ -238,6 +271,11 @@ int bpgpu_last_msm_entries(uint64_t* entries);
 /* Duration (HIP events on the library's stream) of the kernels of the last inner-product, scalar-fold
  * or generator-fold launch: what bench.py prices against the HBM roofline for the scalar kernels. */
 int bpgpu_last_op_ms(float* ms);
+/* Group operations of the last generator-fold launch on the primary context, summed over its lanes:
+ * [0] outputs, [1] doublings, [2] mixed additions (non-zero digits of the recoded shared multipliers, plus
+ * the final P + ...), [3] kernel (1 k_fold_monic, 2 k_fold_joint4, 3 k_fold_points): what bench.py prices
+ * the fold kernels with. */
+int bpgpu_last_fold_ops(uint64_t out[4]);
 /* Sustained v_mad_u64_u32 issue rate (lane-ops/s) measured by a register-only loop:
  * the integer roofline bench.py prices the MSM against. */
 int bpgpu_measure_mad_peak(double* mads_per_sec);

@@ -1,5 +1,6 @@
 """No-GPU checks of the boundary: the C-ABI library loads, exports every symbol that
 include/bpgpu.h declares, and fails loudly (no CPU fallback) when used without a device."""
+import ctypes
 import os
 import re
 
@@ -34,6 +35,23 @@ def test_no_fallback_without_init():
         ffi.msm(0, np.zeros((1, 12), np.uint64), np.zeros((1, 4), np.uint64))
     with pytest.raises(ffi.BpGpuError):
         ffi.ip(0, np.zeros((1, 4), np.uint64), np.zeros((1, 4), np.uint64))
+
+
+def test_size_limits_are_rejected_before_any_device_work():
+    """32-bit guards of the bucket sort: over-long inputs are an argument error, with or without a
+    GPU -- the check precedes every device call, so null data pointers are never touched."""
+    lib = ffi.load()
+    out = np.zeros(9, np.uint64)
+    h = ctypes.c_void_p()
+    big_msm, big_ipa = (1 << 28) + 1, (1 << 26) + 1
+    assert lib.bpgpu_msm(0, None, None, big_msm, out.ctypes.data) == -1
+    assert b"2^28" in lib.bpgpu_last_error()
+    assert lib.bpgpu_msm_affine(0, None, None, big_msm, out.ctypes.data) == -1
+    assert lib.bpgpu_msm_device(0, None, None, big_msm, out.ctypes.data) == -1
+    assert lib.bpgpu_ipa_begin(0, None, None, None, None, None, big_ipa, ctypes.byref(h)) == -1
+    assert b"2^26" in lib.bpgpu_last_error()
+    assert lib.bpgpu_ipa_begin_device(0, None, None, None, None, None, big_ipa, ctypes.byref(h)) == -1
+    assert lib.bpgpu_sharded_init(0, None) == -1 and lib.bpgpu_sharded_init(65, None) == -1
 
 
 def test_product_never_imports_oracle():
