@@ -267,6 +267,7 @@ struct Ctx {
   uint64_t msm_entries = 0;  // non-zero digits of the last MSM batch = bucket-accumulation additions
   uint64_t fold_ops[4] = {};  // last generator-fold launch: outputs, doublings, mixed additions (all lanes), kernel kind
   int open_sessions = 0;     // IPA sessions that still point at this context
+  uint32_t* noalloc_scratch = nullptr;  // this device's copy of the file-scope scratch array (bpgpu_ip_device_noalloc)
   // MSM workspace (grow-only)
   DevBuf counts, offs, order, cursor, canon, ent_idx, ent_fine, sorted, bsum, partial, winsum, heavy, bcount, redtmp;
   // staging for host-buffer entry points
@@ -1224,6 +1225,12 @@ const char* bpgpu_last_error(void) { return g_err.c_str(); }
 // ---- contexts ------------------------------------------------------------------
 }  // extern "C"
 
+// Scratch of bpgpu_ip_device_noalloc: block partial sums of k_ip_partial (up to 1024 blocks x 32 B) followed
+// by nothing else.  File-scope device memory, one copy per GPU for the life of the process; host code only
+// ever uses the per-device address that ctx_init obtains with hipGetSymbolAddress.
+constexpr uint32_t NOALLOC_IP_BLOCKS = 1024;
+static __device__ __align__(256) uint32_t scratch[NOALLOC_IP_BLOCKS * 8];
+
 namespace {
 // caller holds C.mu (or is the only one who can see C)
 int ctx_init(Ctx& C, int device) {
@@ -1238,6 +1245,10 @@ int ctx_init(Ctx& C, int device) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   C.num_cus = prop.multiProcessorCount;
   C.device = device;
+  // this device's copy of the allocation-free entry point's scratch array (each GPU has its own address)
+  void* sp = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+  C.noalloc_scratch = (uint32_t*)sp;
   C.helper.start();
   C.ready = true;
   return 0;
@@ -1260,6 +1271,7 @@ void ctx_release(Ctx& C) {
   for (auto& e : C.ev) (void)hipEventDestroy(e);
   for (auto& e : C.op_ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(C.stream);
+  C.noalloc_scratch = nullptr;
   C.ready = false;
 }
 }  // namespace
@@ -2347,6 +2359,31 @@ void bpgpu_ipa_free(bpgpu_ipa* s) {
     if (s->d_sc) (void)hipFree(s->d_sc);
   }
   delete s;
+}
+
+// ---- allocation-free inner product ---------------------------------------------------------
+// bpgpu_ip_device for callers that cannot allocate: the block partial sums go to this device's copy of the
+// file-scope `scratch` array (address taken once per context in ctx_init) instead of a grow-only hipMalloc'd
+// buffer, the result goes to caller-owned device memory, and nothing here (or below it) calls hipMalloc,
+// hipFree or any allocating routine.  Calls on one GPU share that GPU's array: they are serialised per context
+// by the context mutex, but two contexts on one GPU (or another process's copy of the library) must not overlap
+// such calls on the same device -- documented in bpgpu.h.  Every partial the second kernel reads is written by
+// the first in the same call, so nothing needs clearing between calls.
+int bpgpu_ip_device_noalloc(int curve, const void* d_a, const void* d_b, size_t n, void* d_out) {
+  if (n > BPGPU_IP_NOALLOC_MAX_N) return fail(BPGPU_E_ARG, "n = %zu: bpgpu_ip_device_noalloc takes at most 2^32 - 1 elements", n);
+  CtxLock lk;
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (!d_out) return fail(BPGPU_E_ARG, "null output");
+  if (n && (!d_a || !d_b)) return fail(BPGPU_E_ARG, "null pointer");
+  Ctx& C = cx();
+  if (!C.noalloc_scratch) return fail(BPGPU_E_STATE, "scratch array address missing");
+  static_assert(NOALLOC_IP_BLOCKS >= 1024, "ip_blocks() returns up to 1024 blocks");
+  IpPair p0{0u, 0u};
+  TRY(ip_launch_with(curve, (const uint32_t*)d_a, (const uint32_t*)d_b, p0, p0, 1, (uint32_t)n, C.noalloc_scratch,
+                     (uint32_t*)d_out, (uint32_t*)d_out));
+  HIP_TRY(hipStreamSynchronize(C.stream));
+  return 0;
 }
 
 // ---- sharded (multi-GPU) MSM, one process ------------------------------------------------------

@@ -63,6 +63,7 @@ SIGNATURES = {
     "bpgpu_ipa_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bpgpu_ipa_free": (None, [c_void_p]),
     "bpgpu_points_sum": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
+    "bpgpu_ip_device_noalloc": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_sharded_init": (c_int, [c_int, c_void_p]),
     "bpgpu_sharded_count": (c_int, []),
     "bpgpu_msm_sharded": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -349,6 +350,11 @@ def ip_device(curve, d_a, d_b, n):
     out = np.zeros(4, dtype=np.uint64)
     _check(load().bpgpu_ip_device(curve, d_a.ptr, d_b.ptr, n, _ptr(out)))
     return out
+
+
+def ip_device_noalloc(curve, d_a, d_b, n, d_out):
+    """bpgpu_ip_device without any allocation: the result lands in the caller's device buffer d_out (32 B)."""
+    _check(load().bpgpu_ip_device_noalloc(curve, d_a.ptr, d_b.ptr, n, d_out.ptr))
 
 
 def sharded_init(devices):

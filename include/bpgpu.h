@@ -116,6 +116,16 @@ int bpgpu_points_from_device(int curve, const void* d_points, size_t n, uint64_t
 int bpgpu_msm_device(int curve, const void* d_points, const void* d_scalars, size_t n,
                      uint64_t out_xy_inf[9]);
 int bpgpu_ip_device(int curve, const void* d_a, const void* d_b, size_t n, uint64_t out[4]);
+/* bpgpu_ip_device for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs; the
+ * result (one ark-form scalar, 32 B) is written to caller-owned DEVICE memory d_out; the block partial sums
+ * live in a fixed 32 KiB file-scope device array instead of a grow-only workspace, and the call performs no
+ * hipMalloc / hipFree / allocating library routine.  n <= BPGPU_IP_NOALLOC_MAX_N, larger n is BPGPU_E_ARG.
+ * Every call on a GPU shares that GPU's array: calls through one context are serialised by the library, but
+ * calls that overlap on one GPU from two contexts (bpgpu_sharded_init with a repeated device) or two
+ * processes' worth of streams race on it.  Returns after the stream has drained. */
+#define BPGPU_IP_NOALLOC_MAX_N ((size_t)0xffffffffu)
+int bpgpu_ip_device_noalloc(int curve, const void* d_a, const void* d_b, size_t n, void* d_out);
 int bpgpu_fold_scalars_device(int curve, const void* d_v, size_t n_out, const uint64_t s_lo[4],
                               const uint64_t s_hi[4], void* d_out);
 int bpgpu_fold_points_device(int curve, const void* d_g, size_t n_out, const uint64_t s_lo[4],

@@ -51,6 +51,7 @@ def test_size_limits_are_rejected_before_any_device_work():
     assert lib.bpgpu_ipa_begin(0, None, None, None, None, None, big_ipa, ctypes.byref(h)) == -1
     assert b"2^26" in lib.bpgpu_last_error()
     assert lib.bpgpu_ipa_begin_device(0, None, None, None, None, None, big_ipa, ctypes.byref(h)) == -1
+    assert lib.bpgpu_ip_device_noalloc(0, None, None, 1 << 32, None) == -1
     assert lib.bpgpu_sharded_init(0, None) == -1 and lib.bpgpu_sharded_init(65, None) == -1
 
 
