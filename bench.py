@@ -36,14 +36,14 @@ sys.path.insert(0, ROOT)
 #    Jacobian add = 11 field muls, doubling = 7, full add = 16;
 #  * what the compiled kernels execute (curve.cuh / field.cuh: 9 x 29-bit limbs, p = 2^254 + t): a product is 81
 #    mads (a square 45), a Montgomery reduction 45; XYZZ mixed add madd-2008-s = 6 products + 2 squares + one
-#    two-product accumulation (Y3) with 9 reductions = 1143 mads; doubling dbl-2008-s-1 = 6 products + 3 squares
-#    (Y3 two products, one reduction) with 8 reductions = 1062 mads.
+#    two-product accumulation (Y3) with 9 reductions = 1143 mads; doubling dbl-2008-s-1 = 4 products + 3 squares
+#    (Y3 two products, one reduction) with 8 reductions = 981 mads.
 # `frac` uses the yardstick (comparable across implementations); `frac_executed` uses the second count.
 MADS_PER_FIELD_MUL = 136
 MULS_PER_MIXED_ADD = 11
 MULS_PER_DOUBLE = 7
 EXEC_MADS_MIXED_ADD = 6 * 81 + 2 * 45 + 2 * 81 + 9 * 45   # 1143
-EXEC_MADS_DOUBLE = 5 * 81 + 3 * 45 + 2 * 81 + 8 * 45      # 1062
+EXEC_MADS_DOUBLE = 4 * 81 + 3 * 45 + 2 * 81 + 8 * 45      # 981
 EXEC_MADS_FIELD_MUL = 81 + 45                              # 126
 
 
@@ -382,7 +382,7 @@ def fold_kernels_leg(ffi, curve, log2n, mad_peak):
         buf.free()
     out["note"] = ("group operations executed by the launch (doublings = length of the recoded shared multipliers, mixed additions = "
                    "their non-zero digits + 1) x SURVEY 8(d) costs (7 / 11 field muls x 136 mads); frac_executed uses the compiled "
-                   "counts (1062 / 1143 mads); the batched inversion back to affine (about 9 multiplications per output) is not counted")
+                   "counts (981 / 1143 mads); the batched inversion back to affine (about 9 multiplications per output) is not counted")
     return out
 
 

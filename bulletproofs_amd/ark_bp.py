@@ -51,6 +51,14 @@ def msm(curve, bases, scalars):
     return out
 
 
+def bos_coster_msm(curve, bases, scalars):
+    """util::msm::bos_coster_msm (src/util/msm.rs:34-81): serial heap algorithm, runs on the host (no GPU needed)."""
+    b, s = _u64(bases, 12), _u64(scalars, 4)
+    out = np.zeros(12, np.uint64)
+    _check(load().arkbp_bos_coster_msm(curve, _p(b), c_size_t(len(b)), _p(s), c_size_t(len(s)), _p(out)))
+    return out
+
+
 def ip(curve, a, b):
     a, b = _u64(a, 4), _u64(b, 4)
     out = np.zeros(4, np.uint64)

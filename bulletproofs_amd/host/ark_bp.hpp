@@ -15,7 +15,9 @@
 //   test_rng, Fp256 / point sampling, sample_from_length   examples/msm_bench.rs:40-44, src/lib.rs:111-118,
 //                                                          src/relations/ipa.rs:28-36,90-97,110-115
 //   util::naive_msm (msm_bench's default algorithm)        src/util/msm.rs:13-24
+//   util::bos_coster_msm (serial heap algorithm, host only) src/util/msm.rs:34-81
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
@@ -490,6 +492,94 @@ G naive_msm(const std::vector<G>& bases, const std::vector<Fr>& scalars) {
   check(bpgpu_hadamard_points(CURVE, n ? bases.data()->v : nullptr, n ? scalars.data()->v : nullptr, n,
                               n ? prods.data()->v : nullptr));
   return sum_points<CURVE>(prods);
+}
+// bos_coster_msm (util/msm.rs:34-81): a serial max-heap algorithm, CPU-only in the reference and here (SURVEY 8
+// row a3: it has no data-parallel form; it exists for `msm_bench -m boscoster`).  Entries (x, g) are ordered
+// by x alone (msm.rs:26-32); zero scalars are skipped (:42); the loop pops the two largest and either halves
+// the first (:57-67) or subtracts the second from it while adding the points (:68-75); the last entry is
+// multiplied out (:77-80).  Group operations run on the host (host_field.h); the result is normalised like
+// every other group element that leaves this interface.
+template <int CURVE>
+G bos_coster_msm(const std::vector<G>& bases, const std::vector<Fr>& scalars) {
+  using HFs = bpgpu::host::HF<1 - CURVE>;
+  using HFq = bpgpu::host::HF<CURVE>;
+  using E = bpgpu::host::HEc<CURVE>;
+  using P = bpgpu::host::HPoint<CURVE>;
+  using H4 = bpgpu::host::H4;
+  struct Entry {
+    H4 x;  // canonical scalar (into_repr)
+    P g;
+  };
+  auto cmp = [](const H4& a, const H4& b) {
+    for (int i = 3; i >= 0; i--)
+      if (a.v[i] != b.v[i]) return a.v[i] < b.v[i] ? -1 : 1;
+    return 0;
+  };
+  auto less = [&](const Entry& a, const Entry& b) { return cmp(a.x, b.x) < 0; };
+  auto div2 = [](H4& a) {
+    for (int i = 0; i < 4; i++) a.v[i] = (a.v[i] >> 1) | (i < 3 ? a.v[i + 1] << 63 : 0);
+  };
+  auto is_zero = [](const H4& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; };
+  auto load = [](const uint64_t* w) {
+    H4 r;
+    std::memcpy(r.v, w, 32);
+    return r;
+  };
+  std::vector<Entry> heap;
+  const size_t n = bases.size() < scalars.size() ? bases.size() : scalars.size();  // zip
+  for (size_t i = 0; i < n; i++) {
+    const H4 x = HFs::to_canon(load(scalars[i].v));
+    if (is_zero(x)) continue;
+    heap.push_back(Entry{x, E::from_jacobian(load(bases[i].v), load(bases[i].v + 4), load(bases[i].v + 8))});
+    std::push_heap(heap.begin(), heap.end(), less);
+  }
+  auto pop = [&] {
+    std::pop_heap(heap.begin(), heap.end(), less);
+    Entry e = heap.back();
+    heap.pop_back();
+    return e;
+  };
+  auto push = [&](const Entry& e) {
+    heap.push_back(e);
+    std::push_heap(heap.begin(), heap.end(), less);
+  };
+  while (heap.size() > 1) {
+    Entry first = pop(), second = pop();
+    H4 half_first = first.x;
+    div2(half_first);
+    if (cmp(half_first, second.x) > 0) {
+      push(second);
+      if (first.x.v[0] & 1) push(Entry{H4{{1, 0, 0, 0}}, first.g});
+      div2(first.x);
+      first.g = E::dbl(first.g);
+      push(first);
+    } else {
+      unsigned __int128 br = 0;
+      for (int i = 0; i < 4; i++) {
+        unsigned __int128 d = (unsigned __int128)first.x.v[i] - second.x.v[i] - br;
+        first.x.v[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+      }
+      if (br) throw Panic("assertion failed: !first.x.sub_noborrow(&second.x)");  // msm.rs:69
+      second.g = E::add(first.g, second.g);
+      push(second);
+      if (!is_zero(first.x)) push(first);
+    }
+  }
+  P total = E::identity();
+  if (!heap.empty()) total = E::mul_canon(heap[0].g, heap[0].x);
+  G out;
+  H4 x, y;
+  const H4 one = HFq::one();
+  if (E::to_affine(total, x, y)) {
+    std::memcpy(out.v, x.v, 32);
+    std::memcpy(out.v + 4, y.v, 32);
+    std::memcpy(out.v + 8, one.v, 32);
+  } else {  // zero() = (0, 1, 0)
+    std::memset(out.v, 0, 96);
+    std::memcpy(out.v + 4, one.v, 32);
+  }
+  return out;
 }
 // ---- sparse products of the Com-R1CS compiler (src/relations/com_r1cs.rs:43-83) -------------------
 // ark-relations' Matrix<F>: a list of rows of (value, column) pairs

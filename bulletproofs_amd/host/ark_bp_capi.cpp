@@ -219,6 +219,16 @@ int arkbp_msm(int curve, const uint64_t* bases, size_t nb, const uint64_t* scala
     return 0;
   });
 }
+// util::msm::bos_coster_msm (host-only heap algorithm, src/util/msm.rs:34-81); out: 12 x u64
+int arkbp_bos_coster_msm(int curve, const uint64_t* bases, size_t nb, const uint64_t* scalars, size_t ns, uint64_t* out) {
+  return guarded([&] {
+    std::vector<G> b((const G*)bases, (const G*)bases + nb);
+    std::vector<Fr> s((const Fr*)scalars, (const Fr*)scalars + ns);
+    G g = curve == 0 ? util::bos_coster_msm<0>(b, s) : util::bos_coster_msm<1>(b, s);
+    std::memcpy(out, g.v, 96);
+    return 0;
+  });
+}
 int arkbp_ip(int curve, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out) {
   return guarded([&] {
     Fr r = curve == 0 ? util::ip<0>((const Fr*)a, na, (const Fr*)b, nb) : util::ip<1>((const Fr*)a, na, (const Fr*)b, nb);

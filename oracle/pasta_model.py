@@ -702,6 +702,73 @@ def bp_prove(c: Curve, inst: IpaInstance, wit: IpaWitness, fs: FiatShamirRng) ->
     return BpProof(ls, rs, a[0], b[0], challs)
 
 
+def point_bytes_raw(p: Jac) -> bytes:
+    """ToBytes for GroupProjective as the UNMODIFIED reference uses it (ref: src/proofs/bp_iter.rs:84-85, ark-ec 0.3
+    [UPSTREAM-RECALLED]): the raw Jacobian coordinates X || Y || Z, each as its canonical integer."""
+    return fe_bytes(p[0]) + fe_bytes(p[1]) + fe_bytes(p[2])
+
+
+@dataclass
+class BpProofRaw:
+    ls: List[Jac]  # raw Jacobian representatives, exactly as ark-ec's addition sequence leaves them
+    rs: List[Jac]
+    final_a: int
+    final_b: int
+    challenges: List[int]
+
+
+def bp_prove_faithful_z(c: Curve, inst: IpaInstance, wit: IpaWitness, fs: FiatShamirRng) -> BpProofRaw:
+    """"Faithful-Z" mode: what this model predicts an UNMODIFIED reference computes (ref: src/proofs/bp_iter.rs:49-128).
+    Nothing is normalised: L and R are the raw Jacobian outputs of pippenger_msm (ark-ec's add-2007-bl / dbl-2009-l
+    sequence, src/util/msm.rs:88-193), they are absorbed as raw X || Y || Z (:84-85), and the folded generators
+    l.mul(&x_inv) + r.mul(&x) (:97-104) stay unnormalised Jacobian inputs of the next round's MSMs.  The GPU path
+    cannot reproduce these bytes (its additions run in another order); the vectors exist so that a maintainer with a
+    Rust toolchain can confirm this restatement -- and with it the third-party behaviour it recalls -- against a real
+    `cargo test`.  The proof it yields is the same group elements / field elements ONLY in round 0; later challenges
+    differ from the normalise-at-boundary transcript."""
+    a = zero_pad_to_two_power(wit.a, 0)
+    b = zero_pad_to_two_power(wit.b, 0)
+    A = zero_pad_to_two_power([to_jac(g) for g in inst.a_gens], JAC_INF)
+    B = zero_pad_to_two_power([to_jac(g) for g in inst.b_gens], JAC_INF)
+    q = to_jac(inst.ip_gen)
+    ls, rs, challs = [], [], []
+    while len(a) > 1:
+        n = len(a) // 2
+        l = msm_pippenger(c, A[n:] + B[:n] + [q], a[:n] + b[n:] + [ip(c, a[:n], b[n:])])
+        r = msm_pippenger(c, A[:n] + B[n:] + [q], a[n:] + b[:n] + [ip(c, a[n:], b[:n])])
+        ls.append(l)
+        rs.append(r)
+        fs.absorb(point_bytes_raw(l))
+        fs.absorb(point_bytes_raw(r))
+        x = fs.rand_scalar(c)
+        x_inv = pow(x, -1, c.r)
+        challs.append(x)
+        a = fold_scalars(c, a, x, x_inv)
+        b = fold_scalars(c, b, x_inv, x)
+        A = fold_points(c, A, x_inv, x)
+        B = fold_points(c, B, x, x_inv)
+    return BpProofRaw(ls, rs, a[0], b[0], challs)
+
+
+def bp_verify_faithful_z(c: Curve, inst: IpaInstance, proof: BpProofRaw, fs: FiatShamirRng) -> bool:
+    """ref: src/proofs/bp_iter.rs:130-178 on a raw-Z proof: the verifier absorbs the proof's points as they are."""
+    A = zero_pad_to_two_power([to_jac(g) for g in inst.a_gens], JAC_INF)
+    B = zero_pad_to_two_power([to_jac(g) for g in inst.b_gens], JAC_INF)
+    challs = []
+    for l, r in zip(proof.ls, proof.rs):
+        fs.absorb(point_bytes_raw(l))
+        fs.absorb(point_bytes_raw(r))
+        challs.append(fs.rand_scalar(c))
+    s = scalars_from_challenges(c, challs)
+    s_inv = scalars_from_challenges(c, [pow(x, -1, c.r) for x in challs])
+    bases = A + B + [to_jac(inst.ip_gen)]
+    scalars = [proof.final_a * v % c.r for v in s] + [proof.final_b * v % c.r for v in s_inv] + [proof.final_a * proof.final_b % c.r]
+    for l, r, x in zip(proof.ls, proof.rs, challs):
+        bases += [l, r]
+        scalars += [(-x * x) % c.r, (-pow(x, -2, c.r)) % c.r]
+    return jac_to_affine(c, msm_pippenger(c, bases, scalars)) == inst.result
+
+
 def scalars_from_challenges(c: Curve, challs: Sequence[int]) -> List[int]:
     """ref: src/proofs/bp_iter.rs:25-42."""
     if len(challs) == 0:

@@ -46,3 +46,22 @@ def test_zero_pad_to_multiple_host():
         assert H.scalars_from_abi(c, ark_bp.pad(0, H.scalars_abi(c, xs), k)) == pm.zero_pad_to_multiple(xs, k, 0)
     with pytest.raises(ark_bp.Panic):   # (len - 1) underflows in the reference
         ark_bp.pad(0, np.zeros((0, 4), np.uint64), 3)
+
+
+@pytest.mark.parametrize("c", [pm.PALLAS, pm.VESTA], ids=lambda c: c.name)
+def test_bos_coster_msm_host(c):
+    """util::msm::bos_coster_msm (src/util/msm.rs:34-81) of the host mirror against the model's Bos-Coster and naive MSM:
+    zero scalars skipped, equal scalars, identity bases, a single entry, the empty input."""
+    for n in [0, 1, 2, 3, 17, 64]:
+        pts = H.rand_points(c, n, 700 + n)
+        xs = H.rand_scalars(c, n, 800 + n)
+        if n >= 3:
+            xs[0], xs[1] = 0, c.r - 1
+        if n >= 17:
+            xs[5] = xs[4]
+            pts[7] = None
+            xs[9] = 1
+        want = pm.jac_to_affine(c, pm.msm_bos_coster(c, [pm.to_jac(p) for p in pts], xs))
+        assert want == pm.jac_to_affine(c, pm.msm_naive(c, [pm.to_jac(p) for p in pts], xs))
+        got = ark_bp.bos_coster_msm(c.curve_id, H.jac_abi(c, pts), H.scalars_abi(c, xs))
+        assert H.jac_from_abi(c, got)[0] == want, n

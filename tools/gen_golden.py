@@ -139,8 +139,43 @@ def prove_cases(c):
     return cases
 
 
+def faithful_z_cases(c):
+    """What the model predicts an UNMODIFIED reference produces for `test_bp_ipa_pallas` (src/lib.rs:253-258:
+    test_ipa(vec![1, 2, 4, 8, 16], 1, Bp) -- the reference's "vesta" test, :260-265, instantiates Pallas too; size 17, the
+    non-power-of-two of :188, is appended here and does not change the five before it): raw Jacobian L, R
+    (canonical X | Y | Z as ToBytes writes them), the challenges and final_a / final_b.  NOT produced by the reference:
+    to be confirmed by a maintainer with `cargo test` (INTEGRATION.md 7 prints the same bytes from Rust)."""
+    cases = []
+    rng = pm.test_rng()  # test_ipa draws every size from ONE rng stream (src/lib.rs:111-118)
+    for n in (1, 2, 4, 8, 16, 17):
+        inst, wit = pm.sample_ipa(c, rng, n)
+        seed = rng.gen_bytes32()
+        pf = pm.bp_prove_faithful_z(c, inst, wit, pm.FiatShamirRng(seed))
+        assert pm.bp_verify_faithful_z(c, inst, pf, pm.FiatShamirRng(seed))
+        raw = lambda pts: [pm.point_bytes_raw(p).hex() for p in pts]
+        cases.append({"n": n, "fs_seed": seed.hex(), "result_xyz_canonical": raw([pm.to_jac(inst.result)])[0],
+                      "ls_xyz_canonical": raw(pf.ls), "rs_xyz_canonical": raw(pf.rs),
+                      "challenges_canonical": [pm.fe_bytes(x).hex() for x in pf.challenges],
+                      "final_a_canonical": pm.fe_bytes(pf.final_a).hex(), "final_b_canonical": pm.fe_bytes(pf.final_b).hex()})
+    return cases
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    os.makedirs(os.path.join(OUT, "faithful_z"), exist_ok=True)
+    for c in (pm.PALLAS, pm.VESTA):
+        doc = {"curve": c.name,
+               "WARNING": "self-generated by this repository's own model (oracle/pasta_model.py, bp_prove_faithful_z); NOT reference "
+                          "output.  It restates what an unmodified ark-bp would print for test_ipa(&[1,2,4,8,16,17], 1, Bp) under the "
+                          "UPSTREAM-RECALLED behaviour of ark-ff/ark-ec/ark-std/ark-marlin 0.3 (SURVEY.md 8c); confirm with cargo test.",
+               "format": "hex of canonical little-endian bytes (into_repr): field element 32 B, point X | Y | Z 96 B raw Jacobian",
+               "recipe": "rng = ark_std::test_rng(); for each size: IpaInstance::sample_from_length, fs_seed = rng.gen::<[u8;32]>() "
+                         "(src/lib.rs:110-118), Bp::prove (src/proofs/bp_iter.rs:49-128)",
+               "test_ipa": faithful_z_cases(c)}
+        path = os.path.join(OUT, "faithful_z", f"{c.name}.json")
+        with open(path, "w") as f:
+            json.dump(doc, f, indent=0)
+        print("wrote", path, os.path.getsize(path), "bytes")
     for c in (pm.PALLAS, pm.VESTA):
         doc = {"curve": c.name, "curve_id": c.curve_id,
                "format": "hex of C-ABI bytes: scalar 32 B, jacobian point 96 B (Z = 1, identity = (0,1,0)); Montgomery limbs",
