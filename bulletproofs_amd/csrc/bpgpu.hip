@@ -94,59 +94,6 @@ struct PinnedBuf {
   }
 };
 
-// One helper thread for the host tail of a two-MSM batch (a fresh std::async thread costs about as
-// much as the work it would take over).
-class Helper {
- public:
-  ~Helper() { stop(); }  // a joinable std::thread must not reach its destructor (process exit without bpgpu_shutdown)
-  void start() {
-    if (th_.joinable()) return;
-    quit_ = false;
-    th_ = std::thread([this] {
-      std::unique_lock<std::mutex> lk(mu_);
-      for (;;) {
-        cv_.wait(lk, [this] { return quit_ || job_; });
-        if (quit_) return;
-        std::function<void()> j = std::move(job_);
-        job_ = nullptr;
-        lk.unlock();
-        j();
-        lk.lock();
-        busy_ = false;
-        done_.notify_all();
-      }
-    });
-  }
-  void stop() {
-    if (!th_.joinable()) return;
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      quit_ = true;
-    }
-    cv_.notify_all();
-    th_.join();
-  }
-  void submit(std::function<void()> j) {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      job_ = std::move(j);
-      busy_ = true;
-    }
-    cv_.notify_all();
-  }
-  void wait() {
-    std::unique_lock<std::mutex> lk(mu_);
-    done_.wait(lk, [this] { return !busy_; });
-  }
-
- private:
-  std::thread th_;
-  std::mutex mu_;
-  std::condition_variable cv_, done_;
-  std::function<void()> job_;
-  bool busy_ = false, quit_ = false;
-};
-
 // N persistent worker threads; run(f) executes f(w) on every worker w and returns when all are done.
 // (The staging copies of a large upload and the per-GPU legs of a sharded MSM: a fresh std::thread per
 // call costs tens of microseconds each and a new HIP thread context.)
@@ -183,14 +130,22 @@ class Pool {
     th_.clear();
   }
   int size() const { return n_; }
-  // one run at a time (callers hold the owning context's mutex, or the registry's for the shard pool)
-  void run(const std::function<void(int)>& f) {
-    std::unique_lock<std::mutex> lk(mu_);
+  // one run at a time (callers hold the owning context's mutex, or the registry's for the shard pool).
+  // begin() starts f(w) on every worker and returns; wait() blocks until all are done; run() = both.
+  void begin(const std::function<void(int)>& f) {
+    std::lock_guard<std::mutex> lk(mu_);
     job_ = f;
     pending_ = n_;
     gen_++;
     cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu_);
     done_.wait(lk, [&] { return pending_ == 0; });
+  }
+  void run(const std::function<void(int)>& f) {
+    begin(f);
+    wait();
   }
 
  private:
@@ -273,7 +228,7 @@ struct Ctx {
   // staging for host-buffer entry points
   DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
   DevBuf aux[6];  // sparse products (row pointers, indices, permutation, values, vector, result), point sampling
-  Helper helper;
+  Pool hpool;  // three host threads that share the Horner tail with the caller's thread
   PinnedBuf h_winsum;  // window sums land here (pinned: the copy is a plain DMA)
   Uploader up;
   // the buffers of the last closed IPA session, kept for the next one (a prover makes proof after proof of
@@ -378,16 +333,20 @@ void write_xy_inf(const host::HPoint<BF>& p, uint64_t out[9]) {
 // Horner combine (msm.rs:177-190), high bit position to low with one doubling per position.
 // Window w contributes its component P at position c w and U_i at position c w + s + i
 // (kernels.cuh, bucket reduction); comps = 2 + nbits points per window (P comes in two halves), ark-form XYZZ words.
+// Only the windows in [w_lo, w_hi) contribute (the doublings run down to position 0 all the same), so that the
+// shares of several host threads simply add up.
 template <int BF>
-host::HPoint<BF> horner(const uint32_t* winsums, int W, int c, int s, int nbits) {
+host::HPoint<BF> horner(const uint32_t* winsums, int W, int c, int s, int nbits, int w_lo = 0, int w_hi = 1 << 30) {
   using E = host::HEc<BF>;
   const int comps = 2 + nbits;
   host::HPoint<BF> total = E::identity();
-  const int top = c * (W - 1) + s + (nbits > 0 ? nbits - 1 : 0);
+  if (w_hi > W) w_hi = W;
+  if (w_lo >= w_hi) return total;
+  const int top = c * (w_hi - 1) + s + (nbits > 0 ? nbits - 1 : 0);
   for (int pos = top; pos >= 0; pos--) {
     total = E::dbl(total);
     int w = pos / c, off = pos - w * c;
-    if (w >= W) continue;
+    if (w < w_lo) continue;  // every component of window w sits in [c w, c w + c - 2]: the filter is exact
     if (off == 0) {
       total = E::add(total, hpoint_from_words<BF>(winsums + 32 * (w * comps)));
       total = E::add(total, hpoint_from_words<BF>(winsums + 32 * (w * comps + 1)));
@@ -553,25 +512,47 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   HIP_TRY(hipMemcpyAsync(C.h_winsum.p, C.winsum.p, ws_bytes, hipMemcpyDeviceToHost, st));
   // total number of sorted entries (bin_start[nbins]) rides along: instrumentation for the roofline
   HIP_TRY(hipMemcpyAsync((char*)C.h_winsum.p + ws_bytes, bin_start + sp.nbins, 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
+  // Horner tail on four host threads (three pool workers and this one): a batch of two MSMs gives each MSM
+  // two threads, a single MSM all four.  Thread g of an MSM takes the windows [g W / G, (g+1) W / G) and
+  // runs its doublings down to bit position 0, so the shares simply add up; the critical path is the 255
+  // doublings plus 1 / G of the additions.  The workers are woken once the accumulation has finished and spin
+  // (for the few hundred microseconds of the bucket reduction) on a flag: a condition-variable wake-up after the
+  // data has arrived costs about as much as the additions it takes over.
+  const uint32_t* hw = (const uint32_t*)C.h_winsum.p;
+  const size_t stride = (size_t)W * comps * 32;
+  const int G = plan.M > 1 ? 2 : 4;
+  host::HPoint<BF> part[4];
+  auto task = [&](int t) {
+    const int m = t / G, g = t % G;
+    if (m >= plan.M) return;
+    part[t] = horner<BF>(hw + m * stride, W, c, s, nbits, g * W / G, (g + 1) * W / G);
+  };
+  HIP_TRY(hipEventSynchronize(C.ev[4]));
+  std::atomic<int> go{0};  // 0: wait, 1: the window sums are in host memory, -1: give up
+  C.hpool.begin([&](int w) {
+    while (go.load(std::memory_order_acquire) == 0) __builtin_ia32_pause();
+    if (go.load(std::memory_order_acquire) == 1) task(w + 1);
+  });
+  hipError_t sync_err = hipStreamSynchronize(st);
+  if (sync_err == hipSuccess) sync_err = hipGetLastError();
+  if (sync_err != hipSuccess) {
+    go.store(-1, std::memory_order_release);
+    C.hpool.wait();
+    return fail(BPGPU_E_HIP, "MSM kernels failed: %s", hipGetErrorString(sync_err));
+  }
   {
     uint32_t e32;
     memcpy(&e32, (const char*)C.h_winsum.p + ws_bytes, 4);
     C.msm_entries = e32;
   }
   auto t0 = std::chrono::steady_clock::now();
-  {
-    // Horner tail: one host thread per MSM of the batch (the second one on a helper thread)
-    const uint32_t* hw = (const uint32_t*)C.h_winsum.p;
-    const size_t stride = (size_t)W * comps * 32;
-    host::HPoint<BF> second;
-    if (plan.M > 1) C.helper.submit([&, hw, stride, W, c, s, nbits] { second = horner<BF>(hw + stride, W, c, s, nbits); });
-    write_xy_inf<BF>(horner<BF>(hw, W, c, s, nbits), out[0]);
-    if (plan.M > 1) {
-      C.helper.wait();
-      write_xy_inf<BF>(second, out[1]);
-    }
+  go.store(1, std::memory_order_release);
+  task(0);
+  C.hpool.wait();
+  for (int m = 0; m < plan.M; m++) {
+    host::HPoint<BF> total = part[m * G];
+    for (int g = 1; g < G; g++) total = host::HEc<BF>::add(total, part[m * G + g]);
+    write_xy_inf<BF>(total, out[m]);
   }
   auto t1 = std::chrono::steady_clock::now();
   float ms;
@@ -1249,7 +1230,7 @@ int ctx_init(Ctx& C, int device) {
   void* sp = nullptr;
   HIP_TRY(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
   C.noalloc_scratch = (uint32_t*)sp;
-  C.helper.start();
+  C.hpool.start(3);
   C.ready = true;
   return 0;
 }
@@ -1267,7 +1248,7 @@ void ctx_release(Ctx& C) {
   C.ipa_pool_busy = false;
   C.h_winsum.release();
   C.up.release();
-  C.helper.stop();
+  C.hpool.stop();
   for (auto& e : C.ev) (void)hipEventDestroy(e);
   for (auto& e : C.op_ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(C.stream);

@@ -323,8 +323,9 @@ struct Fp {
   }
 
   // a^(p-2) by square-and-multiply over the bits of p-2 (p-2 = p - 2, low word
-  // 0xffffffff, second word P32[1]-1 since p == 1 mod 2^32)
-  static BP_HD Fe inv(const Fe& a) {
+  // 0xffffffff, second word P32[1]-1 since p == 1 mod 2^32).  About 385 multiplications; kept as the
+  // cross-check of inv() below (tests) -- the kernels call inv().
+  static BP_HD Fe inv_fermat(const Fe& a) {
     Fe base = carry(a);
     Fe r = one();
     bool started = false;
@@ -339,6 +340,118 @@ struct Fp {
       }
     }
     return r;
+  }
+
+  // Modular inverse by Bernstein-Yang division steps ("safegcd"), about a sixth of the instructions of the
+  // Fermat ladder above and, like it, branch-free (every lane of a wave runs the same schedule).
+  //   divstep(delta, f, g), f odd:  delta > 0 and g odd -> (1 - delta, g, (g - f) / 2)
+  //                                 otherwise           -> (1 + delta, f, (g + (g mod 2) f) / 2)
+  // from (1, p, a) reaches g = 0, f = +-1 within 741 steps for 256-bit inputs (Bernstein-Yang 2019, Thm 11.2);
+  // 26 batches of 29 steps = 754.  A batch only looks at the low 29 bits of f and g and yields an integer
+  // matrix T (entries up to 2^29) with (f, g) <- T (f, g) / 2^29; the same T is applied to (d, e), kept
+  // modulo p with d a = f, e a = g (mod p): the division by 2^29 there adds the multiple of p that clears the
+  // low limb, which is the low limb itself negated because p == 1 (mod 2^29).  All big values are nine
+  // signed 29-bit limbs (limbs 0..7 in [0, 2^29), limb 8 signed) -- the "carried" form of this header.
+  static BP_HD Fe inv(const Fe& a) {
+    const Fe g0 = canon(a);
+    int32_t f[9], g[9], d[9], e[9];
+    BP_UNROLL
+    for (int i = 0; i < 9; i++) {
+      f[i] = (int32_t)C::P29[i];
+      g[i] = g0.l[i];
+      d[i] = 0;
+      e[i] = 0;
+    }
+    e[0] = 1;
+    int32_t delta = 1;
+    for (int it = 0; it < 26; it++) {
+      // ---- 29 division steps on the low bits; T = [[u, v], [q, r]] scaled by 2^29
+      uint32_t fl = (uint32_t)f[0] | ((uint32_t)f[1] << 29), gl = (uint32_t)g[0] | ((uint32_t)g[1] << 29);
+      int32_t u = 1, v = 0, q = 0, r = 0;
+      r = 1;
+      for (int i = 0; i < 29; i++) {
+        const int32_t dpos = (-delta) >> 31;          // -1 iff delta > 0
+        const int32_t godd = -(int32_t)(gl & 1u);     // -1 iff g odd
+        // g += +-f (minus when delta > 0), likewise its matrix row, if g is odd
+        const uint32_t x = (fl ^ (uint32_t)dpos) - (uint32_t)dpos;
+        const int32_t y = (u ^ dpos) - dpos, z = (v ^ dpos) - dpos;
+        gl += x & (uint32_t)godd;
+        q += y & godd;
+        r += z & godd;
+        // swap (f takes the old g) when delta > 0 and g was odd
+        const int32_t sw = dpos & godd;
+        delta = 1 + ((delta ^ sw) - sw);
+        fl += gl & (uint32_t)sw;
+        u += q & sw;
+        v += r & sw;
+        gl >>= 1;
+        u <<= 1;
+        v <<= 1;
+      }
+      // ---- (f, g) <- T (f, g) / 2^29 (exact)
+      {
+        acc_t cf = (acc_t)((int64_t)u * f[0]) + (acc_t)((int64_t)v * g[0]);
+        acc_t cg = (acc_t)((int64_t)q * f[0]) + (acc_t)((int64_t)r * g[0]);
+        cf >>= 29;
+        cg >>= 29;
+        BP_UNROLL
+        for (int i = 1; i < 9; i++) {
+          cf += (acc_t)((int64_t)u * f[i]) + (acc_t)((int64_t)v * g[i]);
+          cg += (acc_t)((int64_t)q * f[i]) + (acc_t)((int64_t)r * g[i]);
+          bp_check_acc(cf);
+          bp_check_acc(cg);
+          f[i - 1] = (int32_t)((uint32_t)cf & MASK29);
+          g[i - 1] = (int32_t)((uint32_t)cg & MASK29);
+          cf >>= 29;
+          cg >>= 29;
+        }
+        bp_check_limb((int64_t)cf);
+        bp_check_limb((int64_t)cg);
+        f[8] = (int32_t)cf;
+        g[8] = (int32_t)cg;
+      }
+      // ---- (d, e) <- T (d, e) / 2^29 (mod p); d, e stay in (-2p, p)
+      {
+        const int32_t sd = d[8] >> 31, se = e[8] >> 31;  // -1 iff negative
+        int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+        acc_t cd = (acc_t)((int64_t)u * d[0]) + (acc_t)((int64_t)v * e[0]);
+        acc_t ce = (acc_t)((int64_t)q * d[0]) + (acc_t)((int64_t)r * e[0]);
+        // the multiple of p that makes the sum divisible by 2^29: p == 1 (mod 2^29), so it is minus the low limb
+        md -= (int32_t)(((uint32_t)cd + (uint32_t)md) & MASK29);
+        me -= (int32_t)(((uint32_t)ce + (uint32_t)me) & MASK29);
+        cd += (acc_t)md;  // p limb 0 = 1
+        ce += (acc_t)me;
+        cd >>= 29;
+        ce >>= 29;
+        BP_UNROLL
+        for (int i = 1; i < 9; i++) {
+          cd += (acc_t)((int64_t)u * d[i]) + (acc_t)((int64_t)v * e[i]);
+          ce += (acc_t)((int64_t)q * d[i]) + (acc_t)((int64_t)r * e[i]);
+          if (C::P29[i] != 0) {
+            cd += (acc_t)((int64_t)md * (int64_t)C::P29[i]);
+            ce += (acc_t)((int64_t)me * (int64_t)C::P29[i]);
+          }
+          bp_check_acc(cd);
+          bp_check_acc(ce);
+          d[i - 1] = (int32_t)((uint32_t)cd & MASK29);
+          e[i - 1] = (int32_t)((uint32_t)ce & MASK29);
+          cd >>= 29;
+          ce >>= 29;
+        }
+        // d, e in (-2p, p): top limbs within (-2^24, 2^23]
+        bp_check_limb((int64_t)cd * 64);
+        bp_check_limb((int64_t)ce * 64);
+        d[8] = (int32_t)cd;
+        e[8] = (int32_t)ce;
+      }
+    }
+    // g = 0 and f = +-1 now (f = +-p, d = 0 when a = 0): the integer inverse is sign(f) d.  The value handed in
+    // is x 2^261, its integer inverse x^-1 2^-261; one multiplication by 2^783 gives x^-1 2^261.
+    const int32_t fneg = f[8] >> 31;
+    Fe res;
+    BP_UNROLL
+    for (int i = 0; i < 9; i++) res.l[i] = (d[i] ^ fneg) - fneg;
+    return mul(res, from_const(C::R3_261));
   }
 };
 

@@ -45,6 +45,8 @@ static int fe_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
       break;
     }
     case 10: r = F::is_zero(F::sub(x, y)) ? F::one() : F::zero(); break;
+    case 11: r = F::inv_fermat(x); break;
+    case 12: r = F::inv(F::sub(F::add(x, x), x)); break;  // lazy (uncarried) operand
     default: return -1;
   }
   F::store_ark(r, wo);

@@ -69,6 +69,17 @@ def test_field_ops(chk, fid):
     for a in vals:
         if a:
             assert fe_op(chk, fid, 4, a, 0) == pow(a, -1, p)
+            assert fe_op(chk, fid, 11, a, 0) == pow(a, -1, p)      # the Fermat ladder, cross-check of the gcd inverse
+            assert fe_op(chk, fid, 12, a, 0) == pow(a, -1, p)      # lazy operand
+    assert fe_op(chk, fid, 4, 0, 0) == 0                            # inv(0) = 0, as the Fermat ladder gives
+    # division steps: values whose gcd run is long or lopsided (powers of two, all-ones, neighbours of p / 2 and of p)
+    hard = [1 << k for k in range(0, 255, 7)] + [(1 << k) - 1 for k in range(2, 255, 11)] + [p - (1 << k) for k in range(0, 250, 13)]
+    hard += [p // 2, p // 2 + 1, p // 3, 2 * p // 3, (p - 1) // 2 - 1, 3, 5, 7, p - 3]
+    hard += [rnd.randrange(p) for _ in range(2000)]
+    for a in hard:
+        a %= p
+        if a:
+            assert fe_op(chk, fid, 4, a, 0) == pow(a, -1, p), hex(a)
     for a, b in pairs[:50]:
         assert fe_op(chk, fid, 9, a, b) == (a + 20 * (a + b)) * b % p
     assert chk.bpchk_failures() == 0, "an int64 accumulator / int32 limb bound was violated"

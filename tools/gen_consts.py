@@ -59,6 +59,7 @@ def emit_field(fid, p, name):
         "C261TO256": pow(2, 256, p),          # montmul261(x*2^261, .) = x*2^256
         "C256TOCANON": 32,                    # montmul261(x*2^256, 2^5) = x
         "C261TOCANON": 1,                     # montmul261(x*2^261, 1) = x
+        "R3_261": pow(2, 783, p),             # montmul261(y, 2^783) = y*2^522: integer inverse of x*2^261 -> x^-1*2^261
         "CANONTO261": pow(2, 522, p),         # montmul261(x, .) = x*2^261
         "B261": 5 * (1 << 261) % p,           # curve coefficient b = 5 in device form
     }
