@@ -848,14 +848,20 @@ S192 s192_from(const uint64_t mag[4], bool neg) {
   return r;
 }
 bool s192_zero(const S192& a) { return (a.w[0] | a.w[1] | a.w[2]) == 0; }
-void s192_sub_small(S192& a, int d) {  // a -= d, d in {-1, 0, 1}
+void s192_sub_small(S192& a, int d) {  // a -= d, |d| <= 2
   if (d == 0) return;
   if (d > 0) {
-    for (int i = 0; i < 3; i++)
-      if (a.w[i]-- != 0) break;
+    const uint64_t old = a.w[0];
+    a.w[0] -= (uint64_t)d;
+    if (old < (uint64_t)d)
+      for (int i = 1; i < 3; i++)
+        if (a.w[i]-- != 0) break;
   } else {
-    for (int i = 0; i < 3; i++)
-      if (++a.w[i] != 0) break;
+    const uint64_t add = (uint64_t)(-d);
+    a.w[0] += add;
+    if (a.w[0] < add)
+      for (int i = 1; i < 3; i++)
+        if (++a.w[i] != 0) break;
   }
 }
 void s192_sar1(S192& a) {
@@ -863,47 +869,40 @@ void s192_sar1(S192& a) {
   a.w[1] = (a.w[1] >> 1) | (a.w[2] << 63);
   a.w[2] = (uint64_t)((int64_t)a.w[2] >> 1);
 }
-// digit (da, db) with z = a + b w congruent to it mod 4, if z is a unit mod 4
-bool unit_mod4(uint32_t a4, uint32_t b4, int& da, int& db) {
-  if (b4 == 0 && (a4 & 1u)) { da = a4 == 1 ? 1 : -1; db = 0; return true; }
-  if (a4 == 0 && (b4 & 1u)) { da = 0; db = b4 == 1 ? 1 : -1; return true; }
-  if (a4 == b4 && (a4 & 1u)) { da = db = a4 == 1 ? 1 : -1; return true; }
-  return false;
+// Width-2 expansion of the Eisenstein integer z = a + b w in base 2.  2 is prime in Z[w], and the twelve odd
+// residues modulo 4 are the six units u in {+-1, +-w, +-(1 + w)} and their products with alpha = 1 - w (the six
+// elements of norm 3: +-(1 - w), +-(1 + 2w), +-(2 + w)).  An odd z takes the digit d congruent to it modulo 4;
+// z - d is then divisible by 4, so the next digit is 0: one position in three is non-zero on average (the
+// unit-only expansion of round 1 had 56 %).  The points of the digits cost no arithmetic given Q and
+// Q' = alpha Q = Q - phi(Q) (one affine addition per generator, set up by the kernel): u Q and u Q' are
+// (zeta^k x, +-y).
+// 4-bit codes, position 0 = least significant:  code & 3: 0 none, 1: x, 2: zeta x, 3: zeta^2 x;
+// code & 4: the point is Q' instead of Q;  code & 8: use -y.
+struct EisDigit {
+  int da, db;     // the digit as a + b w
+  uint32_t code;
+};
+const EisDigit* eis_digit_mod4(uint32_t a4, uint32_t b4) {
+  // unit digits: (1,0) -> x, +y;  (0,1) -> zeta x, +y;  (1,1) = -w^2 -> zeta^2 x, -y;  negatives flip y
+  static const EisDigit D[12] = {
+      {1, 0, 1},  {-1, 0, 1 | 8},  {0, 1, 2},  {0, -1, 2 | 8},  {1, 1, 3 | 8},  {-1, -1, 3},
+      // alpha = 1 - w;  w alpha = 1 + 2w;  (1 + w) alpha = 2 + w: the same three maps applied to Q'
+      {1, -1, 4 | 1}, {-1, 1, 4 | 1 | 8}, {1, 2, 4 | 2}, {-1, -2, 4 | 2 | 8}, {2, 1, 4 | 3 | 8}, {-2, -1, 4 | 3}};
+  for (const EisDigit& d : D)
+    if (((uint32_t)d.da & 3u) == a4 && ((uint32_t)d.db & 3u) == b4) return &d;
+  return nullptr;
 }
-// Base-2 expansion of a + b w with digits 0 and the six units (+-1, +-w, +-(1+w)).  An odd z takes the
-// unit congruent to it mod 4 when there is one (the next digit is then 0); otherwise the sign that
-// leaves an even or unit-mod-4 successor.  About 56% of the positions are non-zero.
 int eisenstein_codes(S192 a, S192 b, uint32_t* codes, int max_positions) {
   int pos = 0;
   while (!(s192_zero(a) && s192_zero(b))) {
     if (pos >= max_positions) return -1;
     const uint32_t a4 = (uint32_t)a.w[0] & 3u, b4 = (uint32_t)b.w[0] & 3u;
-    int da = 0, db = 0;
     if ((a4 | b4) & 1u) {
-      if (!unit_mod4(a4, b4, da, db)) {
-        const int ua = (int)(a4 & 1u), ub = (int)(b4 & 1u);
-        da = ua;
-        db = ub;
-        for (int sgn = 1; sgn >= -1; sgn -= 2) {
-          const int ta = sgn * ua, tb = sgn * ub;
-          const uint32_t na = (uint32_t)((a.w[0] - (uint64_t)(int64_t)ta) >> 1) & 3u;
-          const uint32_t nb = (uint32_t)((b.w[0] - (uint64_t)(int64_t)tb) >> 1) & 3u;
-          int x, y;
-          if (((na | nb) & 1u) == 0 || unit_mod4(na, nb, x, y)) {
-            da = ta;
-            db = tb;
-            break;
-          }
-        }
-      }
-      // (1,0) -> x, +y;  (0,1) -> zeta x, +y;  (1,1) -> zeta^2 x, -y;  negatives flip y
-      uint32_t sel, negy;
-      if (db == 0) { sel = 1; negy = da < 0; }
-      else if (da == 0) { sel = 2; negy = db < 0; }
-      else { sel = 3; negy = da > 0; }
-      codes[pos >> 3] |= (sel | (negy << 3)) << ((pos & 7) * 4);
-      s192_sub_small(a, da);
-      s192_sub_small(b, db);
+      const EisDigit* d = eis_digit_mod4(a4, b4);
+      if (!d) return -1;
+      codes[pos >> 3] |= d->code << ((pos & 7) * 4);
+      s192_sub_small(a, d->da);
+      s192_sub_small(b, d->db);
     }
     s192_sar1(a);
     s192_sar1(b);

@@ -1100,13 +1100,15 @@ __global__ void __launch_bounds__(256) k_fold_points(const uint32_t* __restrict_
 // The prover's session (bpgpu.hip, bpgpu_ipa) writes  x^-1 A_lo + x A_hi = x^-1 (A_lo + x^2 A_hi)  and
 // carries the common factor as a scalar, so a fold is ONE shared-scalar multiplication per pair.
 //   * s = k1 + k2 lambda (GLV) is an Eisenstein integer k1 + k2 w; it is expanded in base 2 with
-//     digits in {0, +-1, +-w, +-(1 + w)} (the units: every odd residue class mod 2 holds one).
-//     The matching points need no arithmetic: phi Q = (zeta x, y) and, because
-//     1 + lambda + lambda^2 = 0,  Q + phi Q = -phi^2 Q = (zeta^2 x, -y).  No table, no inversion.
-//   * the only inversion left (back to affine) is shared by the 256 lanes of the workgroup through
-//     a product tree in LDS.
+//     width 2: the digits are 0, the six units {+-1, +-w, +-(1 + w)} and their products with
+//     alpha = 1 - w (the twelve odd residues modulo 4), so that one position in three is non-zero
+//     (bpgpu.hip, eisenstein_codes).  The points of the unit digits need no arithmetic:
+//     phi Q = (zeta x, y) and, because 1 + lambda + lambda^2 = 0,  Q + phi Q = -phi^2 Q = (zeta^2 x, -y);
+//     those of the other six are the same maps applied to Q' = alpha Q = Q - phi(Q), ONE affine addition
+//     per generator whose inversion (of (zeta - 1) x) is shared by the workgroup.  Q' lives in LDS.
+//   * the inversion back to affine is shared by the 256 lanes of the workgroup through a product tree in LDS.
 // 4-bit codes, position 0 = least significant:  code & 3: 0 none, 1: x, 2: zeta x, 3: zeta^2 x;
-// code & 8: use -y.
+// code & 4: of Q' instead of Q;  code & 8: use -y.
 // ---------------------------------------------------------------------------
 struct MonicPlan {
   uint32_t codes[17];  // up to 136 positions, 8 per word
@@ -1150,6 +1152,25 @@ __device__ __forceinline__ Fe block_inverse_256(const Fe& v, uint32_t (*tree)[9]
   return ld(256 + tid);
 }
 
+// (zeta - 1) x of a finite point: the denominator of the slope of Q - phi(Q); never zero (x != 0, zeta != 1)
+template <int BF>
+__device__ __forceinline__ Fe alpha_den(const Aff& Q, const Fe& zeta) {
+  using F = Fp<BF>;
+  return F::carry(F::sub(F::mul(Q.x, zeta), Q.x));
+}
+// Q' = Q - phi(Q) = (x, y) + (zeta x, -y) for a finite Q, given inv = 1 / ((zeta - 1) x):
+// slope = -2y inv,  x' = slope^2 - (1 + zeta) x = slope^2 + zeta^2 x,  y' = slope (x - x') - y
+template <int BF>
+__device__ __forceinline__ Aff alpha_point(const Aff& Q, const Fe& inv, const Fe& zeta2) {
+  using F = Fp<BF>;
+  Aff r;
+  const Fe lam = F::mul(F::neg(F::add(Q.y, Q.y)), inv);
+  r.x = F::carry(F::add(F::sqr(lam), F::mul(Q.x, zeta2)));
+  r.y = F::carry(F::sub(F::mul(lam, F::sub(Q.x, r.x)), Q.y));
+  r.inf = false;
+  return r;
+}
+
 // Vector y (blockIdx.y = 0 / 1):  o[i] = p[i] + s q[i]  (has_p)  or  s q[i]  (!has_p; p is not read).
 // o may alias p or q: a lane reads its own elements before it writes.
 template <int BF>
@@ -1160,35 +1181,61 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
   using E = Ec<BF>;
   using IO = PointIo<BF>;
   __shared__ uint32_t tree[512][9];
+  __shared__ int32_t qa[45][256];  // Q' of this lane: x', zeta x', zeta^2 x', y', -y' (9 limbs each)
+  const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
   const uint32_t* gp = blockIdx.y == 0 ? p0 : p1;
   const uint32_t* gq = blockIdx.y == 0 ? q0 : q1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
   const MonicPlan* f = &plans.p[blockIdx.y];
+  const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
+  Aff Q;
+  Q.inf = true;
+  if (active) Q = IO::load_dev_affine(gq + 16ull * i);
+  const bool qfin = active && !Q.inf;
+  // x never vanishes on a prime-order curve y^2 = x^3 + 5, so Q, phi Q, phi^2 Q are distinct
+  const Fe ainv = block_inverse_256<BF>(qfin ? alpha_den<BF>(Q, zeta) : F::one(), tree);
   Xyzz acc = E::identity();
-  if (active) {
-    Aff Q = IO::load_dev_affine(gq + 16ull * i);
-    if (!Q.inf) {
-      // x never vanishes on a prime-order curve y^2 = x^3 + 5, so the three points are distinct
-      const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
-      const Fe x2 = F::mul(Q.x, zeta), x3 = F::mul(x2, zeta);
-      const Fe yn = F::carry(F::neg(Q.y));
-      for (int pos = f->len - 1; pos >= 0; pos--) {
-        acc = E::dbl(acc);
-        const uint32_t code = (f->codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;  // wave-uniform
-        const uint32_t sel = code & 3u;
-        if (sel) {
-          Aff t;
-          t.x = sel == 1 ? Q.x : (sel == 2 ? x2 : x3);
-          t.y = (code & 8u) ? yn : Q.y;
-          t.inf = false;
-          E::madd(acc, t);
-        }
+  if (qfin) {
+    const Fe zeta2 = F::sqr(zeta);
+    const Fe x2 = F::mul(Q.x, zeta), x3 = F::mul(Q.x, zeta2);
+    const Fe yn = F::carry(F::neg(Q.y));
+    {
+      const Aff A = alpha_point<BF>(Q, ainv, zeta2);
+      const Fe ax2 = F::mul(A.x, zeta), ax3 = F::mul(A.x, zeta2), ayn = F::carry(F::neg(A.y));
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        qa[k][tid] = A.x.l[k];
+        qa[9 + k][tid] = ax2.l[k];
+        qa[18 + k][tid] = ax3.l[k];
+        qa[27 + k][tid] = A.y.l[k];
+        qa[36 + k][tid] = ayn.l[k];
       }
     }
-    if (has_p) E::madd(acc, IO::load_dev_affine(gp + 16ull * i));
+    for (int pos = f->len - 1; pos >= 0; pos--) {
+      acc = E::dbl(acc);
+      const uint32_t code = (f->codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;  // wave-uniform
+      const uint32_t sel = code & 3u;
+      if (sel) {
+        Aff t;
+        t.inf = false;
+        if (code & 4u) {  // a digit of the alpha orbit: the lane's own column of qa (no other lane touches it)
+          const int xo = 9 * ((int)sel - 1), yo = (code & 8u) ? 36 : 27;
+#pragma unroll
+          for (int k = 0; k < 9; k++) {
+            t.x.l[k] = qa[xo + k][tid];
+            t.y.l[k] = qa[yo + k][tid];
+          }
+        } else {
+          t.x = sel == 1 ? Q.x : (sel == 2 ? x2 : x3);
+          t.y = (code & 8u) ? yn : Q.y;
+        }
+        E::madd(acc, t);
+      }
+    }
   }
+  if (active && has_p) E::madd(acc, IO::load_dev_affine(gp + 16ull * i));
   // back to affine: x = X / ZZ, y = Y / ZZZ with one shared inversion of ZZ * ZZZ
   const bool fin = active && !acc.inf;
   const Fe den = fin ? F::mul(acc.zz, acc.zzz) : F::one();
@@ -1225,18 +1272,47 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
   using E = Ec<BF>;
   using IO = PointIo<BF>;
   __shared__ uint32_t tree[512][9];
+  __shared__ int32_t qa[54][256];  // Q'_t = alpha Q_t of this lane, t = 0..2: x' (9 limbs), y' (9 limbs)
+  const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < q;
   const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
   const Joint4Plan* f = &plans.p[blockIdx.y];
+  const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
+  const Fe zeta2 = F::sqr(zeta);
+  Aff Q0, Q1, Q2;
+  Q0.inf = Q1.inf = Q2.inf = true;
+  if (active) {
+    Q0 = IO::load_dev_affine(g + 16ull * (i + q));
+    Q1 = IO::load_dev_affine(g + 16ull * (i + 2ull * q));
+    Q2 = IO::load_dev_affine(g + 16ull * (i + 3ull * q));
+  }
+  {
+    // Q'_t = Q_t - phi(Q_t): the three slopes share one inversion (and that one the workgroup's)
+    const Fe d0 = Q0.inf ? F::one() : alpha_den<BF>(Q0, zeta);
+    const Fe d1 = Q1.inf ? F::one() : alpha_den<BF>(Q1, zeta);
+    const Fe d2 = Q2.inf ? F::one() : alpha_den<BF>(Q2, zeta);
+    const Fe d01 = F::mul(d0, d1);
+    const Fe iv = block_inverse_256<BF>(F::mul(d01, d2), tree);
+    const Fe i2 = F::mul(iv, d01), i01 = F::mul(iv, d2);
+    const Fe i0 = F::mul(i01, d1), i1 = F::mul(i01, d0);
+#pragma unroll 1
+    for (int t = 0; t < 3; t++) {
+      const Aff& Qt = t == 0 ? Q0 : (t == 1 ? Q1 : Q2);
+      const Fe& it = t == 0 ? i0 : (t == 1 ? i1 : i2);
+      if (!Qt.inf) {
+        const Aff A = alpha_point<BF>(Qt, it, zeta2);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          qa[18 * t + k][tid] = A.x.l[k];
+          qa[18 * t + 9 + k][tid] = A.y.l[k];
+        }
+      }
+    }
+  }
   Xyzz acc = E::identity();
   if (active) {
-    const Aff Q0 = IO::load_dev_affine(g + 16ull * (i + q));
-    const Aff Q1 = IO::load_dev_affine(g + 16ull * (i + 2ull * q));
-    const Aff Q2 = IO::load_dev_affine(g + 16ull * (i + 3ull * q));
-    const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
-    const Fe zeta2 = F::sqr(zeta);
     for (int pos = f->len - 1; pos >= 0; pos--) {
       acc = E::dbl(acc);
 #pragma unroll 1
@@ -1245,9 +1321,17 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
         const uint32_t sel = code & 3u;
         if (sel) {
           Aff p;  // uniform selects, not an indexed array (which would live in scratch)
-          p.x = t == 0 ? Q0.x : (t == 1 ? Q1.x : Q2.x);
-          p.y = t == 0 ? Q0.y : (t == 1 ? Q1.y : Q2.y);
           p.inf = t == 0 ? Q0.inf : (t == 1 ? Q1.inf : Q2.inf);
+          if (code & 4u) {  // a digit of the alpha orbit: the lane's own column of qa
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+              p.x.l[k] = qa[18 * t + k][tid];
+              p.y.l[k] = qa[18 * t + 9 + k][tid];
+            }
+          } else {
+            p.x = t == 0 ? Q0.x : (t == 1 ? Q1.x : Q2.x);
+            p.y = t == 0 ? Q0.y : (t == 1 ? Q1.y : Q2.y);
+          }
           if (sel != 1) p.x = F::mul(p.x, sel == 2 ? zeta : zeta2);
           if (code & 8u) p.y = F::carry(F::neg(p.y));
           E::madd(acc, p);  // skips an identity operand (zero padding)
