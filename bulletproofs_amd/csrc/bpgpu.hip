@@ -234,6 +234,7 @@ struct Ctx {
   // the buffers of the last closed IPA session, kept for the next one (a prover makes proof after proof of
   // one size; hipMalloc + hipFree of 460 MB cost about a millisecond per proof)
   DevBuf ipa_pts, ipa_sc;
+  DevBuf ipa_table, ipa_table_tmp;  // fixed-base table of the pooled session's frozen generators (and its XYZZ staging)
   bool ipa_pool_busy = false;
 };
 
@@ -248,6 +249,7 @@ inline Ctx& cx() { return tl_ctx ? *tl_ctx : g_primary; }
 std::atomic<int> g_window_bits{0};
 std::atomic<size_t> g_freeze_len{1u << 15};  // vectors this short defer the generator fold (0 = never)
 std::atomic<bool> g_pair_fold{true};         // long rounds fold their generators two rounds at a time (k_fold_joint4)
+std::atomic<size_t> g_ipa_table_min{1u << 12};  // frozen generators at least this many get a fixed-base table (0 = never)
 
 // Serialises the calls on the current context; with an explicit context (an IPA session's) that context is
 // also made current for the scope.
@@ -394,8 +396,11 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     out[m][8] = 1;
   }
   if (plan.n == 0) return 0;
-  const int c = choose_window(plan.n_eff ? plan.n_eff : plan.n, plan.M);
+  // fixed-base table mode: the width is the one the table was built for, and all windows of an MSM share a bucket set
+  const bool table = plan.table_stride != 0;
+  const int c = table ? plan.c : choose_window(plan.n_eff ? plan.n_eff : plan.n, plan.M);
   const int W = (256 + c - 1) / c;
+  const int Wb = table ? 1 : W;  // bucket sets per MSM
   plan.c = c;
   plan.W = W;
   // the sort keeps entry positions, bin and bucket offsets in 32 bits, and an entry is index | sign << 31
@@ -403,10 +408,10 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     return fail(BPGPU_E_ARG, "MSM of %d x %u points in %d windows has 2^32 or more (point, window) pairs", plan.M, plan.n, W);
   for (int m = 0; m < plan.M; m++)
     for (int g = 0; g < 3; g++)
-      if ((uint64_t)plan.seg[m][g].pt_off + plan.seg[m][g].count > (1ull << 31))
+      if ((uint64_t)plan.seg[m][g].pt_off + plan.seg[m][g].count + (uint64_t)plan.table_stride * (W - 1) > (1ull << 31))
         return fail(BPGPU_E_ARG, "point index beyond 2^31");
   const uint32_t B = 1u << (c - 1);
-  const uint32_t NB = (uint32_t)plan.M * W * B;
+  const uint32_t NB = (uint32_t)plan.M * Wb * B;
   const uint64_t slots = (uint64_t)plan.M * plan.n;
   // bucket reduction: runs of S = 2^s buckets, at most 8192 runs per window.  Both stages are bound by the
   // number of additions they issue (a lone wave already fills its SIMD's issue slots), so longer runs pay
@@ -414,6 +419,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   int s = c - 1 < 3 ? c - 1 : 3;
   if (NB >= (800u << 10) && c - 1 >= 4) s = 4;
   if (c - 1 - s > 13) s = c - 1 - 13;
+  if (table && c - 1 >= 2) s = 2;  // few buckets: the reduction is a chain of additions, keep it short
   const uint32_t nruns = NB >> s;
   const uint32_t runs_per_window = B >> s;
   const int nbits = c - 1 - s;  // bits of a window-local run index
@@ -422,6 +428,8 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   // two-level counting sort: coarse bins of 2^fine_bits buckets
   SortPlan sp;
   sp.fine_bits = c - 1 < 10 ? c - 1 : 10;
+  // with few buckets in all keep at least 64 bins, so that the LDS histograms do not pile onto a handful of counters
+  while (sp.fine_bits > 0 && (NB >> sp.fine_bits) < 64) sp.fine_bits--;
   sp.nbins = NB >> sp.fine_bits;
   sp.tiles = cdiv(slots, 1024);
   const uint32_t part_grid = sp.tiles < 512 ? sp.tiles : 512;
@@ -439,7 +447,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   TRY(C.sorted.ensure((size_t)slots * W * 4 + 4));
   TRY(C.bsum.ensure((size_t)NB * 128));
   TRY(C.partial.ensure((size_t)nruns * 256));
-  TRY(C.winsum.ensure((size_t)plan.M * W * comps * 128));
+  TRY(C.winsum.ensure((size_t)plan.M * Wb * comps * 128));
   uint32_t* bin_count = C.counts.as<uint32_t>();
   uint32_t* chunk_counter = bin_count + (size_t)sp.nbins * BIN_PAD;  // zeroed with bin_count
   uint32_t* bin_cursor = chunk_counter + 16;
@@ -454,7 +462,11 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   uint64_t floor_t = 4 * entries / lanes;
   if (floor_t < 32) floor_t = 32;
   if (floor_t > HEAVY_T_MIN) floor_t = HEAVY_T_MIN;
-  const uint32_t heavy_t = (uint32_t)(4 * mean_len > floor_t ? 4 * mean_len : floor_t);
+  // far fewer buckets than lanes and long lists (table mode): 2^glog lanes share a bucket, each about a dozen entries
+  int glog = 0;
+  while (glog < 6 && (mean_len >> glog) > 12 && ((uint64_t)NB << (glog + 1)) <= lanes) glog++;
+  const uint64_t lane_len = mean_len >> glog;  // entries a lane walks
+  const uint32_t heavy_t = (uint32_t)((4 * lane_len > floor_t ? 4 * lane_len : floor_t) << glog);
   const size_t max_heavy = (size_t)(entries / heavy_t) + 1, max_pieces = (size_t)(entries / HEAVY_PIECE) + max_heavy;
   TRY(C.heavy.ensure((3 * max_heavy + 2 * max_pieces + 32 * max_pieces) * 4));
   HeavyLists hv;
@@ -488,26 +500,26 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   HIP_TRY(hipEventRecord(C.ev[3], st));
   k_accum<BF><<<C.num_cus * BP_ACCUM_WAVES, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
                                              C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits, hv,
-                                             chunk_counter);
+                                             chunk_counter, glog);
   k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[4], st));
   k_reduce1<BF><<<cdiv(nruns, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
   {
     // slices per component: about 1024 waves in all (one per SIMD), at least one value per lane.  Every
     // slice pays a 6-step wave tree on top of its lanes' sums, so more, shorter slices cost more additions
-    const uint32_t outputs = (uint32_t)(comps * plan.M * W), half = runs_per_window >> 1;
+    const uint32_t outputs = (uint32_t)(comps * plan.M * Wb), half = runs_per_window >> 1;
     uint32_t slices = 1;
     while (slices < 64 && 2 * slices * outputs <= 1024 && 2 * slices * 64 <= half) slices *= 2;
     const uint32_t groups = cdiv(slices, 4);  // a workgroup adds up its four slices itself
     TRY(C.redtmp.ensure((size_t)outputs * groups * 128));
-    k_reduce2<BF><<<dim3(comps, plan.M * W, groups), 256, 0, st>>>(
+    k_reduce2<BF><<<dim3(comps, plan.M * Wb, groups), 256, 0, st>>>(
         C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window, slices);
     if (groups > 1)
       k_reduce3<BF><<<cdiv(outputs * groups, 256), 256, 0, st>>>(C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), outputs,
                                                                   groups);
   }
   HIP_TRY(hipEventRecord(C.ev[5], st));
-  const size_t ws_bytes = (size_t)plan.M * W * comps * 128;
+  const size_t ws_bytes = (size_t)plan.M * Wb * comps * 128;
   TRY(C.h_winsum.ensure(ws_bytes + 16));
   HIP_TRY(hipMemcpyAsync(C.h_winsum.p, C.winsum.p, ws_bytes, hipMemcpyDeviceToHost, st));
   // total number of sorted entries (bin_start[nbins]) rides along: instrumentation for the roofline
@@ -519,13 +531,14 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   // (for the few hundred microseconds of the bucket reduction) on a flag: a condition-variable wake-up after the
   // data has arrived costs about as much as the additions it takes over.
   const uint32_t* hw = (const uint32_t*)C.h_winsum.p;
-  const size_t stride = (size_t)W * comps * 32;
+  const size_t stride = (size_t)Wb * comps * 32;
   const int G = plan.M > 1 ? 2 : 4;
   host::HPoint<BF> part[4];
   auto task = [&](int t) {
     const int m = t / G, g = t % G;
+    part[t] = host::HEc<BF>::identity();
     if (m >= plan.M) return;
-    part[t] = horner<BF>(hw + m * stride, W, c, s, nbits, g * W / G, (g + 1) * W / G);
+    part[t] = horner<BF>(hw + m * stride, Wb, c, s, nbits, g * Wb / G, (g + 1) * Wb / G);
   };
   HIP_TRY(hipEventSynchronize(C.ev[4]));
   std::atomic<int> go{0};  // 0: wait, 1: the window sums are in host memory, -1: give up
@@ -997,6 +1010,9 @@ struct bpgpu_ipa {
   bool lazy;
   bool lazy_off;
   size_t n0;  // length at which the generators stopped being folded
+  // fixed-base table of the frozen generators (kernels.cuh, k_table_*): 2^(c w) of A0 | B0 | Q, stride 2 n0 + 1
+  uint32_t* d_table;  // null: the short rounds run the general MSM over the frozen generators themselves
+  int table_c;
   std::vector<std::array<uint64_t, 8>> pending;  // (x, x^-1) of the folds not applied to the points
   // Common factors of the stored generators: the true vectors are muA * A and muB * B.  A fold
   // x^-1 A_lo + x A_hi is done as A_lo + x^2 A_hi (one scalar multiplication per pair, k_fold_monic)
@@ -1159,6 +1175,7 @@ int ipa_freeze(bpgpu_ipa* s) {
   s->n0 = s->len;
   s->frozen = true;
   s->lazy = false;
+  s->d_table = nullptr;
   s->pending.clear();
   const uint32_t half = (uint32_t)s->freeze_cap;
   FoldScalars m = make_fold_scalars(s->muA, s->muB);
@@ -1167,6 +1184,35 @@ int ipa_freeze(bpgpu_ipa* s) {
   else
     k_frozen_init<0><<<cdiv(2 * half, 256), 256, 0, cx().stream>>>(s->wA(), half, m);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+// Fixed-base table for the rounds that are left (the generators are frozen for good at length n0 = s->len).
+// Worth its doubling chain (about 1.5 ms whatever the size: 240 dependent doublings per lane) only when many
+// rounds follow, and only the pooled session builds one (the table lives in the context's buffers).
+constexpr int TABLE_C = 15;             // 17 windows of 15 bits = the 255 bits of a Pasta scalar: no sparse top window
+int ipa_build_table(bpgpu_ipa* s) {
+  s->d_table = nullptr;
+  const size_t min_len = g_ipa_table_min.load();  // default 2^12: twelve rounds left at least
+  if (min_len == 0 || !s->pooled || !s->frozen || s->lazy || s->n0 < min_len || s->n0 < 2) return 0;
+  Ctx& C = cx();
+  // 18 rows: a scalar at or just below 2^254 (r - 1, say) carries out of window 16 into window 17
+  const int c = TABLE_C, W = (256 + c - 1) / c;
+  const uint32_t n0 = (uint32_t)s->n0, stride = 2 * n0 + 1;
+  TRY(C.ipa_table.ensure((size_t)W * stride * 64));
+  TRY(C.ipa_table_tmp.ensure((size_t)(W - 1) * stride * 128));
+  uint32_t* tab = C.ipa_table.as<uint32_t>();
+  uint32_t* tmp = C.ipa_table_tmp.as<uint32_t>();
+  const uint32_t count = (uint32_t)(W - 1) * stride;
+  if (s->curve == BPGPU_PALLAS) {
+    k_table_chain<0><<<cdiv(stride, 256), 256, 0, C.stream>>>(s->d_pts, (uint32_t)s->np, n0, tab, tmp, c, W);
+    k_table_norm<0><<<cdiv(cdiv(count, TABLE_NORM_BATCH), 256), 256, 0, C.stream>>>(tmp, tab, stride, count);
+  } else {
+    k_table_chain<1><<<cdiv(stride, 256), 256, 0, C.stream>>>(s->d_pts, (uint32_t)s->np, n0, tab, tmp, c, W);
+    k_table_norm<1><<<cdiv(cdiv(count, TABLE_NORM_BATCH), 256), 256, 0, C.stream>>>(tmp, tab, stride, count);
+  }
+  HIP_TRY(hipGetLastError());
+  s->d_table = tab;
+  s->table_c = c;
   return 0;
 }
 // apply the deferred point folds one round at a time (s->len is the CURRENT vector length; the stored
@@ -1244,6 +1290,8 @@ void ctx_release(Ctx& C) {
   for (DevBuf& b : C.aux) b.release();
   C.ipa_pts.release();
   C.ipa_sc.release();
+  C.ipa_table.release();
+  C.ipa_table_tmp.release();
   C.ipa_pool_busy = false;
   C.h_winsum.release();
   C.up.release();
@@ -1302,6 +1350,11 @@ int bpgpu_set_freeze_len(size_t len) {
 
 int bpgpu_set_pair_fold(int enable) {
   g_pair_fold.store(enable != 0);
+  return 0;
+}
+
+int bpgpu_set_ipa_table(size_t min_len) {
+  g_ipa_table_min.store(min_len == 1 ? (size_t)1 << 12 : min_len);
   return 0;
 }
 
@@ -2038,6 +2091,8 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
   s->lazy_off = !g_pair_fold.load() || np < 4;
   s->freeze_cap = s->lazy_off ? s->freeze_thresh : np;  // pair folding freezes at any length
   s->frozen = false;
+  s->d_table = nullptr;
+  s->table_c = 0;
   s->freeze_disabled = freeze_len == 0;
   s->n0 = 0;
   s->sc_scaled = 2 * np + 2 + 6 * s->freeze_cap;
@@ -2108,7 +2163,7 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
       if ((rc = points_in(curve, (uint32_t*)(stg + n * 96), s->d_pts + 16 * np, n, 0)) != 0) break;
       if ((rc = points_in(curve, (uint32_t*)(stg + 2 * n * 96), s->d_pts + 32 * np, 1, 0)) != 0) break;
     }
-    if (np <= s->freeze_thresh && !s->freeze_disabled && np > 1 && (rc = ipa_freeze(s)) != 0) break;
+    if (np <= s->freeze_thresh && !s->freeze_disabled && np > 1 && ((rc = ipa_freeze(s)) != 0 || (rc = ipa_build_table(s)) != 0)) break;
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(BPGPU_E_HIP, "sync failed");
   } while (0);
   if (rc) {
@@ -2197,13 +2252,20 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
     HIP_TRY(hipGetLastError());
     plan.n = 2 * n0 + 1;
     plan.n_eff = n0 + 1;  // half of the weighted scalars are zero by construction (k_frozen_scalars)
+    const bool tab = s->d_table != nullptr && !s->lazy;
+    // point indices: the session's A | B | Q array, or the table's compact A0 | B0 | Q rows
+    const uint32_t pB = tab ? n0 : np, pQ = tab ? 2 * n0 : 2 * np;
+    if (tab) {
+      plan.table_stride = 2 * n0 + 1;
+      plan.c = s->table_c;
+    }
     plan.seg[0][0] = MsmSeg{0u, fs, n0};
-    plan.seg[0][1] = MsmSeg{np, fs + n0, n0};
-    plan.seg[0][2] = MsmSeg{2 * np, 2 * np, 1};
+    plan.seg[0][1] = MsmSeg{pB, fs + n0, n0};
+    plan.seg[0][2] = MsmSeg{pQ, 2 * np, 1};
     plan.seg[1][0] = MsmSeg{0u, fs + 2 * n0, n0};
-    plan.seg[1][1] = MsmSeg{np, fs + 3 * n0, n0};
-    plan.seg[1][2] = MsmSeg{2 * np, 2 * np + 1, 1};
-    TRY(msm_dispatch(s->curve, s->d_pts, s->d_sc, plan, out));
+    plan.seg[1][1] = MsmSeg{pB, fs + 3 * n0, n0};
+    plan.seg[1][2] = MsmSeg{pQ, 2 * np + 1, 1};
+    TRY(msm_dispatch(s->curve, tab ? s->d_table : s->d_pts, s->d_sc, plan, out));
     memcpy(l_xy_inf, out[0], 72);
     memcpy(r_xy_inf, out[1], 72);
     s->lr_done = true;
@@ -2278,7 +2340,10 @@ int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv
   }
   s->len = n;
   s->lr_done = false;
-  if (!s->frozen && !s->freeze_disabled && n > 1 && n <= s->freeze_thresh) IPA_TRY(ipa_freeze(s));
+  if (!s->frozen && !s->freeze_disabled && n > 1 && n <= s->freeze_thresh) {
+    IPA_TRY(ipa_freeze(s));
+    IPA_TRY(ipa_build_table(s));
+  }
   IPA_HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }

@@ -30,6 +30,11 @@ struct MsmPlan {
   int c;       // window width in bits; digits are signed, |d| <= 2^(c-1)
   uint32_t n;  // slots per MSM (sum of its segment counts)
   uint32_t n_eff;  // slots whose scalar can be non-zero, if the caller knows (0 = n): sizes the windows
+  // Fixed-base table mode (0 = off): the point array holds, for every point index p < table_stride, its multiples
+  // 2^(c w) P at index w * table_stride + p (w < W).  Window w of a slot then takes the w-th multiple, every
+  // window's digits fall into ONE bucket set per MSM (W times fewer buckets to reduce) and the window sum needs
+  // no doublings.  c is then given by the caller (the width the table was built for).
+  uint32_t table_stride;
   MsmSeg seg[2][3];
 };
 
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, 
       uint32_t mag = neg ? (1u << c) - bits : bits;
       carry = neg;
       dp[(uint64_t)j * plan.n] = mag | (neg << 31);
-      if (mag) atomicAdd(&cnt[(((uint32_t)(m * W + j) << (c - 1)) + (mag - 1)) >> sp.fine_bits], 1u);
+      if (mag) atomicAdd(&cnt[(((uint32_t)(plan.table_stride ? m : m * W + j) << (c - 1)) + (mag - 1)) >> sp.fine_bits], 1u);
     }
   }
   __syncthreads();
@@ -216,6 +221,8 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
   const uint32_t tid = threadIdx.x;
   const uint32_t wj = blockIdx.y;  // m*W + j
   const int m = (int)(wj / (uint32_t)plan.W);
+  const uint32_t wb = plan.table_stride ? (uint32_t)m : wj;                            // bucket set of this window
+  const uint32_t tab_off = plan.table_stride * (wj - (uint32_t)m * (uint32_t)plan.W);  // this window's multiples
   const uint32_t nbw = 1u << (plan.c - 1 - sp.fine_bits);  // coarse bins per window
   const uint32_t fine_mask = (1u << sp.fine_bits) - 1u;
   const uint32_t t0 = blockIdx.x * PART_TILE;
@@ -241,7 +248,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
   const uint32_t loff = wg_excl_scan_1024(v, wsum, total);
   uint32_t g = 0;
   if (tid < nbw && v) {
-    uint32_t b = wj * nbw + tid;
+    uint32_t b = wb * nbw + tid;
     g = bin_start[b] + atomicAdd(&bin_cursor[(uint64_t)b * BIN_PAD], v);
   }
   gdst[tid] = g - loff;
@@ -261,7 +268,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter(MsmPlan plan, SortPlan sp
     }
     uint32_t lb = (d - 1) >> sp.fine_bits;
     uint32_t p = atomicAdd(&cnt[lb], 1u);
-    buf[p] = (plan.seg[m][s].pt_off + r) | (dv & 0x80000000u);
+    buf[p] = (plan.seg[m][s].pt_off + r + tab_off) | (dv & 0x80000000u);
     bfine[p] = (uint16_t)((d - 1) & fine_mask);
     bbin[p] = (uint16_t)lb;
   }
@@ -443,6 +450,26 @@ __device__ __forceinline__ Xyzz wave_sum_xyzz(Xyzz acc) {
   return acc;
 }
 
+// sums over aligned groups of 2*first lanes (first a power of two), result valid in each group's first lane
+template <int BF>
+__device__ __forceinline__ Xyzz group_sum_xyzz(Xyzz acc, int first) {
+  using E = Ec<BF>;
+#pragma unroll 1
+  for (int off = first; off >= 1; off >>= 1) {
+    Xyzz o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      o.x.l[i] = __shfl_down(acc.x.l[i], off, 64);
+      o.y.l[i] = __shfl_down(acc.y.l[i], off, 64);
+      o.zz.l[i] = __shfl_down(acc.zz.l[i], off, 64);
+      o.zzz.l[i] = __shfl_down(acc.zzz.l[i], off, 64);
+    }
+    o.inf = __shfl_down((int)acc.inf, off, 64) != 0;
+    acc = E::add(acc, o);
+  }
+  return acc;
+}
+
 // Bucket accumulation.  BF = base field id.  Persistent waves: the grid is sized to the chip
 // (2 waves per SIMD) and every wave pulls work items from a shared counter until none is left
 // (bounded loop; every wave reaches item >= total and leaves).  Items, longest first:
@@ -452,6 +479,9 @@ __device__ __forceinline__ Xyzz wave_sum_xyzz(Xyzz acc) {
 //   * chunks of 64 ordinary buckets, one per lane: chunk k is the (k / nbins)-th group of 64
 //     buckets, in decreasing size, of bin k % nbins (k_bin_offsets' order[]), so lanes of a wave
 //     walk lists of near-equal length and the kernel's tail is made of the shortest lists.
+//     When there are far fewer buckets than lanes (fixed-base table mode: one bucket set for all windows,
+//     lists of a hundred entries and more) G = 2^glog lanes share a bucket: a chunk is 64 / G buckets, a
+//     lane strides its bucket's list by G and the G partial sums are added up by lane shuffles.
 #ifndef BP_ACCUM_WAVES
 #define BP_ACCUM_WAVES 2  // persistent waves per SIMD (tuning knob; also the launch bound)
 #endif
@@ -459,11 +489,13 @@ template <int BF>
 __global__ void __launch_bounds__(256, BP_ACCUM_WAVES) k_accum(const uint32_t* __restrict__ points, const uint32_t* __restrict__ offs,
                                                const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                uint32_t* __restrict__ bsum, uint32_t nbuckets, uint32_t nbins,
-                                               int fine_bits, HeavyLists hv, uint32_t* __restrict__ work_counter) {
+                                               int fine_bits, HeavyLists hv, uint32_t* __restrict__ work_counter, int glog) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t nchunks = (nbuckets + 63u) >> 6;
+  const uint32_t per = 64u >> glog;  // buckets per chunk
+  const uint32_t sub = lane & ((1u << glog) - 1u), slot = lane >> glog;
+  const uint32_t nchunks = (nbuckets + per - 1u) / per;
   const uint32_t npieces = hv.counters[1];
   const uint32_t total = npieces + nchunks;
   const uint32_t F = 1u << fine_bits;
@@ -482,18 +514,20 @@ __global__ void __launch_bounds__(256, BP_ACCUM_WAVES) k_accum(const uint32_t* _
       step = 64;
     } else {
       uint32_t kc = k - npieces, gid;
-      if (F >= 64u) {
+      if (F >= per) {
         uint32_t pos = kc / nbins, bin = kc - pos * nbins;
-        gid = bin * F + pos * 64u + lane;
+        gid = bin * F + pos * per + slot;
       } else {
-        gid = kc * 64u + lane;
+        gid = kc * per + slot;
       }
-      act = gid < nbuckets;
+      act = gid < nbuckets && (F < per || (kc / nbins) * per + slot < F);
       if (act) {
         b = order[gid];
         lo = offs[b];
         hi = offs[b + 1];
         act = hi - lo <= hv.threshold;  // longer lists were cut into pieces
+        lo += sub;
+        step = 1u << glog;
       }
       if (!act) hi = lo;
     }
@@ -526,8 +560,9 @@ __global__ void __launch_bounds__(256, BP_ACCUM_WAVES) k_accum(const uint32_t* _
     if (piece) {  // wave-uniform
       acc = wave_sum_xyzz<BF>(acc);
       if (lane == 0) IO::store_dev_xyzz(hv.psum + 32ull * k, acc);
-    } else if (act) {
-      IO::store_dev_xyzz(bsum + 32ull * b, acc);
+    } else {
+      if (glog) acc = group_sum_xyzz<BF>(acc, 1 << (glog - 1));  // wave-uniform; every lane takes part
+      if (act && sub == 0) IO::store_dev_xyzz(bsum + 32ull * b, acc);
     }
   }
 }
@@ -1349,6 +1384,78 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
     r.x = F::mul(acc.x, F::mul(inv, acc.zzz));
     r.y = F::mul(acc.y, F::mul(inv, acc.zz));
     IO::store_dev_affine(o + 16ull * i, r);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fixed-base table of the prover's frozen generators (MsmPlan::table_stride).  The short rounds of a proof run
+// fifteen pairs of MSMs over the SAME points; with the multiples 2^(c w) P at hand every window's digits share
+// one bucket set and the host tail has nothing to double.
+//   k_table_chain: one lane per point (A0 | B0 | Q, `stride` = 2 n0 + 1 of them): copies P to window 0 and
+//                  walks the doubling chain, leaving 2^(c w) P for w = 1 .. W-1 in XYZZ form (tmp);
+//   k_table_norm:  one lane per (w, point): XYZZ -> affine with the workgroup-shared inversion.
+// ---------------------------------------------------------------------------
+template <int BF>
+__global__ void __launch_bounds__(256) k_table_chain(const uint32_t* __restrict__ pts, uint32_t np, uint32_t n0,
+                                                     uint32_t* __restrict__ table, uint32_t* __restrict__ tmp, int c, int W) {
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  const uint32_t stride = 2 * n0 + 1;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= stride) return;
+  const uint64_t src = j < n0 ? j : (j < 2 * n0 ? (uint64_t)np + (j - n0) : 2ull * np);
+  const Aff P = IO::load_dev_affine(pts + 16ull * src);
+  IO::store_dev_affine(table + 16ull * j, P);
+  Xyzz acc = E::from_affine(P);
+  for (int w = 1; w < W; w++) {
+    for (int k = 0; k < c; k++) acc = E::dbl(acc);
+    IO::store_dev_xyzz(tmp + 32ull * ((uint64_t)(w - 1) * stride + j), acc);
+  }
+}
+
+// A lane converts TABLE_NORM_BATCH elements (e, e + quarter, ...) with one inversion of its own -- the product of
+// their denominators -- and that one is shared by the workgroup: four times fewer workgroup inversions, whose
+// single-lane root inversion is what this kernel waits for.
+constexpr int TABLE_NORM_BATCH = 4;
+template <int BF>
+__global__ void __launch_bounds__(256) k_table_norm(const uint32_t* __restrict__ tmp, uint32_t* __restrict__ table,
+                                                    uint32_t stride, uint32_t count) {
+  using F = Fp<BF>;
+  using IO = PointIo<BF>;
+  __shared__ uint32_t tree[512][9];
+  const uint32_t quarter = (count + TABLE_NORM_BATCH - 1) / TABLE_NORM_BATCH;
+  const uint32_t e0 = blockIdx.x * blockDim.x + threadIdx.x;
+  // prefix products of the denominators zz * zzz (1 for identity / absent elements)
+  Fe pre[TABLE_NORM_BATCH];
+  Fe run = F::one();
+#pragma unroll
+  for (int k = 0; k < TABLE_NORM_BATCH; k++) {
+    const uint64_t e = (uint64_t)e0 + (uint64_t)k * quarter;
+    pre[k] = run;
+    if (e0 < quarter && e < count) {
+      const Xyzz p = IO::load_dev_xyzz(tmp + 32ull * e);
+      if (!p.inf) run = F::mul(run, F::mul(p.zz, p.zzz));
+    }
+  }
+  Fe inv = block_inverse_256<BF>(run, tree);  // 1 / (product of this lane's denominators)
+#pragma unroll
+  for (int k = TABLE_NORM_BATCH - 1; k >= 0; k--) {
+    const uint64_t e = (uint64_t)e0 + (uint64_t)k * quarter;
+    if (e0 < quarter && e < count) {
+      const Xyzz p = IO::load_dev_xyzz(tmp + 32ull * e);
+      Aff r;
+      r.inf = p.inf;
+      r.x = F::zero();
+      r.y = F::zero();
+      if (!p.inf) {
+        const Fe den = F::mul(p.zz, p.zzz);
+        const Fe ik = F::mul(inv, pre[k]);  // 1 / den
+        inv = F::mul(inv, den);             // drop this element from the running inverse
+        r.x = F::mul(p.x, F::mul(ik, p.zzz));
+        r.y = F::mul(p.y, F::mul(ik, p.zz));
+      }
+      IO::store_dev_affine(table + 16ull * ((uint64_t)stride + e), r);
+    }
   }
 }
 

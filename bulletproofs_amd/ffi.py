@@ -25,6 +25,7 @@ SIGNATURES = {
     "bpgpu_set_window_bits": (c_int, [c_int]),
     "bpgpu_set_freeze_len": (c_int, [c_size_t]),
     "bpgpu_set_pair_fold": (c_int, [c_int]),
+    "bpgpu_set_ipa_table": (c_int, [c_size_t]),
     "bpgpu_msm": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_msm_affine": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_ip": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -131,6 +132,11 @@ def set_window_bits(c: int):
 
 def set_pair_fold(enable: bool):
     _check(load().bpgpu_set_pair_fold(1 if enable else 0))
+
+
+def set_ipa_table(min_len: int):
+    """0 = never build the short rounds' fixed-base table, 1 = default threshold, n = build from n frozen generators."""
+    _check(load().bpgpu_set_ipa_table(int(min_len)))
 
 
 def set_freeze_len(n: int):

@@ -66,6 +66,11 @@ int bpgpu_set_freeze_len(size_t len);
 /* IPA sessions fold the generators of their long rounds two rounds at a time ("pair
  * folding"; default on).  Tuning only: results are identical either way. */
 int bpgpu_set_pair_fold(int enable);
+/* IPA sessions build a fixed-base table (the multiples 2^(15 w) of the generators as they are when folding stops)
+ * for their short rounds when those generators number at least min_len ("fixed-base table"): 0 = never,
+ * 1 = the default (2^12: twelve rounds left at least), otherwise the threshold itself.  Tuning only: results are
+ * identical either way. */
+int bpgpu_set_ipa_table(size_t min_len);
 
 /* ---- variable-base MSM ------------------------------------------------------
  * Replaces `pippenger_msm` (= `crate::util::msm`), reference src/util/msm.rs:88-193

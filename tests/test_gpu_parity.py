@@ -250,12 +250,14 @@ def test_msm_2_24_sharded_like_eight_gpus(ffi):
     assert int(got[8]) == 0 and (got[:8] == want[:8]).all()
 
 
+@pytest.mark.parametrize("table", [0, 2], ids=["notable", "table"])
 @pytest.mark.parametrize("pair", [True, False], ids=["pairfold", "roundfold"])
 @pytest.mark.parametrize("freeze", [0, 2, 8, 64, 1 << 15])
-def test_bp_prove_deferred_fold_equivalence(ffi, freeze, pair):
-    """Deferring the generator fold (frozen generators + challenge-product weights) and folding two rounds
-    at a time (k_fold_joint4) change nothing: same L, R, final scalars and exported generators for every
-    freeze length, with and without pair folding, against the oracle."""
+def test_bp_prove_deferred_fold_equivalence(ffi, freeze, pair, table):
+    """Deferring the generator fold (frozen generators + challenge-product weights), folding two rounds
+    at a time (k_fold_joint4) and running the short rounds over a fixed-base table of the frozen generators
+    (one bucket set for all windows, several lanes per bucket) change nothing: same L, R, final scalars and
+    exported generators for every freeze length, with and without pair folding, against the oracle."""
     from oracle import c_oracle as co
     c = pm.PALLAS
     n = 64
@@ -263,6 +265,7 @@ def test_bp_prove_deferred_fold_equivalence(ffi, freeze, pair):
     ls, rs, ch, fa, fb = co.bp_prove(0, A, B, q, a, b, seed, threads=4)
     ffi.set_freeze_len(freeze)
     ffi.set_pair_fold(pair)
+    ffi.set_ipa_table(table)
     try:
         sess = ffi.IpaSession(0, A, B, q, a, b)
         k = 0
@@ -287,10 +290,11 @@ def test_bp_prove_deferred_fold_equivalence(ffi, freeze, pair):
     finally:
         ffi.set_freeze_len(1 << 15)
         ffi.set_pair_fold(True)
+        ffi.set_ipa_table(1)
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("n,freeze", [(2048, 16), (1000, 0), (4096, 256), (512, 2)])
+@pytest.mark.parametrize("n,freeze", [(2048, 16), (1000, 0), (4096, 256), (512, 2), (4096, 1 << 15), (1000, 1 << 15)])
 def test_pair_folding_whole_proofs(ffi, c, n, freeze):
     """Sizes the oracle still proves in seconds: the proof with pair folding (two challenges applied by one
     k_fold_joint4 pass, odd and even numbers of long rounds, zero padding at n = 1000) equals the proof
@@ -305,8 +309,9 @@ def test_pair_folding_whole_proofs(ffi, c, n, freeze):
     ls, rs, ch, fa, fb = co.bp_prove(cid, Ap, Bp, q, np.concatenate([a, zs]), np.concatenate([b, zs]), seed, threads=8)
     ffi.set_freeze_len(freeze)
     try:
-        for pair in (True, False):
+        for pair, table in ((True, 2), (False, 2), (True, 0)):
             ffi.set_pair_fold(pair)
+            ffi.set_ipa_table(table)  # a table whenever the generators freeze for good (also from the start)
             sess = ffi.IpaSession(cid, A, B, q, a, b)
             k = 0
             while len(sess) > 1:
@@ -320,6 +325,7 @@ def test_pair_folding_whole_proofs(ffi, c, n, freeze):
     finally:
         ffi.set_freeze_len(1 << 15)
         ffi.set_pair_fold(True)
+        ffi.set_ipa_table(1)
 
 
 @pytest.mark.parametrize("pair", [False, True], ids=["roundfold", "pairfold"])
