@@ -1199,7 +1199,7 @@ int ipa_build_table(bpgpu_ipa* s) {
   const int c = TABLE_C, W = (256 + c - 1) / c;
   const uint32_t n0 = (uint32_t)s->n0, stride = 2 * n0 + 1;
   TRY(C.ipa_table.ensure((size_t)W * stride * 64));
-  TRY(C.ipa_table_tmp.ensure((size_t)(W - 1) * stride * 128));
+  TRY(C.ipa_table_tmp.ensure((size_t)(W - 1) * stride * 96));
   uint32_t* tab = C.ipa_table.as<uint32_t>();
   uint32_t* tmp = C.ipa_table_tmp.as<uint32_t>();
   const uint32_t count = (uint32_t)(W - 1) * stride;

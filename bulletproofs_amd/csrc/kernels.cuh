@@ -1231,7 +1231,7 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
   const bool qfin = active && !Q.inf;
   // x never vanishes on a prime-order curve y^2 = x^3 + 5, so Q, phi Q, phi^2 Q are distinct
   const Fe ainv = block_inverse_256<BF>(qfin ? alpha_den<BF>(Q, zeta) : F::one(), tree);
-  Xyzz acc = E::identity();
+  Jac acc = E::jidentity();  // Jacobian: the chain is mostly doublings
   if (qfin) {
     const Fe zeta2 = F::sqr(zeta);
     const Fe x2 = F::mul(Q.x, zeta), x3 = F::mul(Q.x, zeta2);
@@ -1249,7 +1249,7 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
       }
     }
     for (int pos = f->len - 1; pos >= 0; pos--) {
-      acc = E::dbl(acc);
+      acc = E::jdbl(acc);
       const uint32_t code = (f->codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;  // wave-uniform
       const uint32_t sel = code & 3u;
       if (sel) {
@@ -1266,22 +1266,15 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
           t.x = sel == 1 ? Q.x : (sel == 2 ? x2 : x3);
           t.y = (code & 8u) ? yn : Q.y;
         }
-        E::madd(acc, t);
+        E::jmadd(acc, t);
       }
     }
   }
-  if (active && has_p) E::madd(acc, IO::load_dev_affine(gp + 16ull * i));
-  // back to affine: x = X / ZZ, y = Y / ZZZ with one shared inversion of ZZ * ZZZ
+  if (active && has_p) E::jmadd(acc, IO::load_dev_affine(gp + 16ull * i));
+  // back to affine: x = X / Z^2, y = Y / Z^3 with one shared inversion of Z
   const bool fin = active && !acc.inf;
-  const Fe den = fin ? F::mul(acc.zz, acc.zzz) : F::one();
-  const Fe inv = block_inverse_256<BF>(den, tree);
-  if (active) {
-    Aff r;
-    r.inf = !fin;
-    r.x = F::mul(acc.x, F::mul(inv, acc.zzz));
-    r.y = F::mul(acc.y, F::mul(inv, acc.zz));
-    IO::store_dev_affine(o + 16ull * i, r);
-  }
+  const Fe inv = block_inverse_256<BF>(fin ? acc.z : F::one(), tree);
+  if (active) IO::store_dev_affine(o + 16ull * i, E::jto_affine_with(acc, inv));
 }
 
 // ---------------------------------------------------------------------------
@@ -1346,10 +1339,10 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
       }
     }
   }
-  Xyzz acc = E::identity();
+  Jac acc = E::jidentity();  // Jacobian: the chain is mostly doublings
   if (active) {
     for (int pos = f->len - 1; pos >= 0; pos--) {
-      acc = E::dbl(acc);
+      acc = E::jdbl(acc);
 #pragma unroll 1
       for (int t = 0; t < 3; t++) {
         const uint32_t code = (f->m[t].codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;  // wave-uniform
@@ -1369,22 +1362,15 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
           }
           if (sel != 1) p.x = F::mul(p.x, sel == 2 ? zeta : zeta2);
           if (code & 8u) p.y = F::carry(F::neg(p.y));
-          E::madd(acc, p);  // skips an identity operand (zero padding)
+          E::jmadd(acc, p);  // skips an identity operand (zero padding)
         }
       }
     }
-    E::madd(acc, IO::load_dev_affine(g + 16ull * i));
+    E::jmadd(acc, IO::load_dev_affine(g + 16ull * i));
   }
   const bool fin = active && !acc.inf;
-  const Fe den = fin ? F::mul(acc.zz, acc.zzz) : F::one();
-  const Fe inv = block_inverse_256<BF>(den, tree);
-  if (active) {
-    Aff r;
-    r.inf = !fin;
-    r.x = F::mul(acc.x, F::mul(inv, acc.zzz));
-    r.y = F::mul(acc.y, F::mul(inv, acc.zz));
-    IO::store_dev_affine(o + 16ull * i, r);
-  }
+  const Fe inv = block_inverse_256<BF>(fin ? acc.z : F::one(), tree);
+  if (active) IO::store_dev_affine(o + 16ull * i, E::jto_affine_with(acc, inv));
 }
 
 // ---------------------------------------------------------------------------
@@ -1392,8 +1378,8 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
 // fifteen pairs of MSMs over the SAME points; with the multiples 2^(c w) P at hand every window's digits share
 // one bucket set and the host tail has nothing to double.
 //   k_table_chain: one lane per point (A0 | B0 | Q, `stride` = 2 n0 + 1 of them): copies P to window 0 and
-//                  walks the doubling chain, leaving 2^(c w) P for w = 1 .. W-1 in XYZZ form (tmp);
-//   k_table_norm:  one lane per (w, point): XYZZ -> affine with the workgroup-shared inversion.
+//                  walks the doubling chain (Jacobian: cheapest doubling), leaving 2^(c w) P for w = 1 .. W-1 in tmp;
+//   k_table_norm:  lanes over the (w, point) elements: Jacobian -> affine with the workgroup-shared inversion.
 // ---------------------------------------------------------------------------
 template <int BF>
 __global__ void __launch_bounds__(256) k_table_chain(const uint32_t* __restrict__ pts, uint32_t np, uint32_t n0,
@@ -1406,10 +1392,10 @@ __global__ void __launch_bounds__(256) k_table_chain(const uint32_t* __restrict_
   const uint64_t src = j < n0 ? j : (j < 2 * n0 ? (uint64_t)np + (j - n0) : 2ull * np);
   const Aff P = IO::load_dev_affine(pts + 16ull * src);
   IO::store_dev_affine(table + 16ull * j, P);
-  Xyzz acc = E::from_affine(P);
+  Jac acc = E::jfrom_affine(P);
   for (int w = 1; w < W; w++) {
-    for (int k = 0; k < c; k++) acc = E::dbl(acc);
-    IO::store_dev_xyzz(tmp + 32ull * ((uint64_t)(w - 1) * stride + j), acc);
+    for (int k = 0; k < c; k++) acc = E::jdbl(acc);
+    IO::store_dev_jac(tmp + 24ull * ((uint64_t)(w - 1) * stride + j), acc);
   }
 }
 
@@ -1425,7 +1411,8 @@ __global__ void __launch_bounds__(256) k_table_norm(const uint32_t* __restrict__
   __shared__ uint32_t tree[512][9];
   const uint32_t quarter = (count + TABLE_NORM_BATCH - 1) / TABLE_NORM_BATCH;
   const uint32_t e0 = blockIdx.x * blockDim.x + threadIdx.x;
-  // prefix products of the denominators zz * zzz (1 for identity / absent elements)
+  // prefix products of the denominators Z (1 for identity / absent elements)
+  using E = Ec<BF>;
   Fe pre[TABLE_NORM_BATCH];
   Fe run = F::one();
 #pragma unroll
@@ -1433,8 +1420,8 @@ __global__ void __launch_bounds__(256) k_table_norm(const uint32_t* __restrict__
     const uint64_t e = (uint64_t)e0 + (uint64_t)k * quarter;
     pre[k] = run;
     if (e0 < quarter && e < count) {
-      const Xyzz p = IO::load_dev_xyzz(tmp + 32ull * e);
-      if (!p.inf) run = F::mul(run, F::mul(p.zz, p.zzz));
+      const Jac p = IO::load_dev_jac(tmp + 24ull * e);
+      if (!p.inf) run = F::mul(run, p.z);
     }
   }
   Fe inv = block_inverse_256<BF>(run, tree);  // 1 / (product of this lane's denominators)
@@ -1442,19 +1429,13 @@ __global__ void __launch_bounds__(256) k_table_norm(const uint32_t* __restrict__
   for (int k = TABLE_NORM_BATCH - 1; k >= 0; k--) {
     const uint64_t e = (uint64_t)e0 + (uint64_t)k * quarter;
     if (e0 < quarter && e < count) {
-      const Xyzz p = IO::load_dev_xyzz(tmp + 32ull * e);
-      Aff r;
-      r.inf = p.inf;
-      r.x = F::zero();
-      r.y = F::zero();
+      const Jac p = IO::load_dev_jac(tmp + 24ull * e);
+      Fe zi = F::one();
       if (!p.inf) {
-        const Fe den = F::mul(p.zz, p.zzz);
-        const Fe ik = F::mul(inv, pre[k]);  // 1 / den
-        inv = F::mul(inv, den);             // drop this element from the running inverse
-        r.x = F::mul(p.x, F::mul(ik, p.zzz));
-        r.y = F::mul(p.y, F::mul(ik, p.zz));
+        zi = F::mul(inv, pre[k]);   // 1 / Z
+        inv = F::mul(inv, p.z);     // drop this element from the running inverse
       }
-      IO::store_dev_affine(table + 16ull * ((uint64_t)stride + e), r);
+      IO::store_dev_affine(table + 16ull * ((uint64_t)stride + e), E::jto_affine_with(p, zi));
     }
   }
 }

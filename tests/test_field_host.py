@@ -124,8 +124,9 @@ def test_point_ops(chk, curve):
         ([], None),
     ]
     for plist, signs in cases:
-        for mode in (0, 1, 3):
+        for mode in (0, 1, 3, 4):
             assert run(mode, plist, signs) == expect(plist, signs), (mode, signs)
     for k in [0, 1, 2, 3, 0xFFFFFFFFFFFFFFFF, 0x123456789ABCDEF]:
         assert run(2, [pts[4]], None, k) == pm.aff_mul(curve, pts[4], k)
+        assert run(5, [pts[4]], None, k) == pm.aff_mul(curve, pts[4], k << 200)   # Jacobian ladder + 200 doublings
     assert chk.bpchk_failures() == 0
