@@ -219,6 +219,7 @@ struct Ctx {
   hipEvent_t op_ev[2] = {};  // around the last ip / fold launch (bpgpu_last_op_ms)
   int num_cus = 256;
   float msm_ms[8] = {};
+  bool msm_timed = false;  // ev[0..5] bracket the phases of a completed MSM
   uint64_t msm_entries = 0;  // non-zero digits of the last MSM batch = bucket-accumulation additions
   uint64_t fold_ops[4] = {};  // last generator-fold launch: outputs, doublings, mixed additions (all lanes), kernel kind
   int open_sessions = 0;     // IPA sessions that still point at this context
@@ -447,7 +448,14 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   TRY(C.sorted.ensure((size_t)slots * W * 4 + 4));
   TRY(C.bsum.ensure((size_t)NB * 128));
   TRY(C.partial.ensure((size_t)nruns * 256));
-  TRY(C.winsum.ensure((size_t)plan.M * Wb * comps * 128));
+  // The window sums (and the number of sorted entries: instrumentation for the roofline) are written by the last
+  // kernels straight into pinned host memory, which the device addresses over PCIe: no copy command between the
+  // reduction and the host tail.
+  const size_t ws_bytes = (size_t)plan.M * Wb * comps * 128;
+  TRY(C.h_winsum.ensure(ws_bytes + 16));
+  uint32_t* d_winsum = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&d_winsum, C.h_winsum.p, 0));
+  uint32_t* d_entries = d_winsum + ws_bytes / 4;
   uint32_t* bin_count = C.counts.as<uint32_t>();
   uint32_t* chunk_counter = bin_count + (size_t)sp.nbins * BIN_PAD;  // zeroed with bin_count
   uint32_t* bin_cursor = chunk_counter + 16;
@@ -487,7 +495,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4 + 64, st));
   k_part_count<SF><<<part_grid, 1024, lds_bytes, st>>>(plan, sp, d_scalars, C.canon.as<uint32_t>(), bin_count);
   HIP_TRY(hipEventRecord(C.ev[1], st));
-  k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, tile_start, bin_cursor, sp.nbins);
+  k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, tile_start, bin_cursor, sp.nbins, d_entries);
   k_part_scatter<<<dim3(cdiv(plan.n, PART_TILE), plan.M * W), 1024, 0, st>>>(
       plan, sp, C.canon.as<uint32_t>(), bin_start, bin_cursor, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>());
   HIP_TRY(hipEventRecord(C.ev[2], st));
@@ -513,17 +521,11 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     const uint32_t groups = cdiv(slices, 4);  // a workgroup adds up its four slices itself
     TRY(C.redtmp.ensure((size_t)outputs * groups * 128));
     k_reduce2<BF><<<dim3(comps, plan.M * Wb, groups), 256, 0, st>>>(
-        C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), runs_per_window, slices);
+        C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), d_winsum, runs_per_window, slices);
     if (groups > 1)
-      k_reduce3<BF><<<cdiv(outputs * groups, 256), 256, 0, st>>>(C.redtmp.as<uint32_t>(), C.winsum.as<uint32_t>(), outputs,
-                                                                  groups);
+      k_reduce3<BF><<<cdiv(outputs * groups, 256), 256, 0, st>>>(C.redtmp.as<uint32_t>(), d_winsum, outputs, groups);
   }
   HIP_TRY(hipEventRecord(C.ev[5], st));
-  const size_t ws_bytes = (size_t)plan.M * Wb * comps * 128;
-  TRY(C.h_winsum.ensure(ws_bytes + 16));
-  HIP_TRY(hipMemcpyAsync(C.h_winsum.p, C.winsum.p, ws_bytes, hipMemcpyDeviceToHost, st));
-  // total number of sorted entries (bin_start[nbins]) rides along: instrumentation for the roofline
-  HIP_TRY(hipMemcpyAsync((char*)C.h_winsum.p + ws_bytes, bin_start + sp.nbins, 4, hipMemcpyDeviceToHost, st));
   // Horner tail on four host threads (three pool workers and this one): a batch of two MSMs gives each MSM
   // two threads, a single MSM all four.  Thread g of an MSM takes the windows [g W / G, (g+1) W / G) and
   // runs its doublings down to bit position 0, so the shares simply add up; the critical path is the 255
@@ -568,21 +570,8 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     write_xy_inf<BF>(total, out[m]);
   }
   auto t1 = std::chrono::steady_clock::now();
-  float ms;
-  HIP_TRY(hipEventElapsedTime(&ms, C.ev[0], C.ev[1]));
-  C.msm_ms[0] = ms;
-  HIP_TRY(hipEventElapsedTime(&ms, C.ev[1], C.ev[2]));
-  C.msm_ms[1] = ms;
-  HIP_TRY(hipEventElapsedTime(&ms, C.ev[2], C.ev[3]));
-  C.msm_ms[2] = ms;
-  HIP_TRY(hipEventElapsedTime(&ms, C.ev[3], C.ev[4]));
-  C.msm_ms[3] = ms;
-  C.msm_ms[4] = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, C.ev[4], C.ev[5]));
-  C.msm_ms[5] = ms;
   C.msm_ms[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-  HIP_TRY(hipEventElapsedTime(&ms, C.ev[0], C.ev[5]));
-  C.msm_ms[7] = ms;
+  C.msm_timed = true;  // the GPU phases are read off the events when bpgpu_last_msm_timings asks
   return 0;
 }
 
@@ -2638,7 +2627,15 @@ int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t o
 int bpgpu_last_msm_timings(float out_ms[8]) {
   if (!out_ms) return fail(BPGPU_E_ARG, "null pointer");
   CtxLock lk;
-  memcpy(out_ms, cx().msm_ms, sizeof cx().msm_ms);
+  Ctx& C = cx();
+  if (C.ready && C.msm_timed) {
+    HIP_TRY(hipSetDevice(C.device));
+    const int span[6][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {0, 5}};
+    const int slot[6] = {0, 1, 2, 3, 5, 7};
+    for (int i = 0; i < 6; i++) HIP_TRY(hipEventElapsedTime(&C.msm_ms[slot[i]], C.ev[span[i][0]], C.ev[span[i][1]]));
+    C.msm_ms[4] = 0;
+  }
+  memcpy(out_ms, C.msm_ms, sizeof C.msm_ms);
   return 0;
 }
 

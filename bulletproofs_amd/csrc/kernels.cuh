@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, 
 constexpr uint32_t BIN_TILE = 16384;
 __global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t* __restrict__ bin_count, uint32_t* __restrict__ bin_start,
                                                    uint32_t* __restrict__ tile_start, uint32_t* __restrict__ bin_cursor,
-                                                   uint32_t nbins) {
+                                                   uint32_t nbins, uint32_t* __restrict__ total_out) {
   __shared__ uint32_t part[1024];
   __shared__ uint32_t tpart[1024];
   uint32_t tid = threadIdx.x;
@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t* __restrict__ 
   if (tid == 1023) {
     bin_start[nbins] = part[1023];
     tile_start[nbins] = tpart[1023];
+    *total_out = part[1023];  // number of sorted entries, for the host (pinned memory)
   }
 }
 
