@@ -143,6 +143,8 @@ __global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, 
     Fe v = F::mul(F::unpack(w), F::from_const(F::C::C256TOCANON));
     F::pack(F::canon(v), w);
     uint32_t carry = 0;
+    // bucket set of window j: m W + j, or m alone in table mode (all windows share one set)
+    const uint32_t wb0 = plan.table_stride ? (uint32_t)m : (uint32_t)(m * W), wbs = plan.table_stride ? 0u : 1u;
     uint32_t* dp = dig + (uint64_t)m * W * plan.n + t;
     for (int j = 0; j < W; j++) {
       uint32_t bits = extract_bits(w, j * c, c) + carry;
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, 
       uint32_t mag = neg ? (1u << c) - bits : bits;
       carry = neg;
       dp[(uint64_t)j * plan.n] = mag | (neg << 31);
-      if (mag) atomicAdd(&cnt[(((uint32_t)(plan.table_stride ? m : m * W + j) << (c - 1)) + (mag - 1)) >> sp.fine_bits], 1u);
+      if (mag) atomicAdd(&cnt[(((wb0 + wbs * (uint32_t)j) << (c - 1)) + (mag - 1)) >> sp.fine_bits], 1u);
     }
   }
   __syncthreads();
