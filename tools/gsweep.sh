@@ -1,0 +1,12 @@
+#!/bin/bash
+# dev: MSM timing against the number of windows in the first group (0 = no split)
+L=${1:-20}; shift
+for g in "$@"; do
+echo "== log2n=$L g0=$g"
+BPGPU_DBG_G0=$g timeout -k 10 200 python bench.py --log2n $L --grown-points --no-cpu-baseline --ipa-log2n 0 --steps 20 | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); print(round(d['value']/1e6,1), 'Mpts/s', round(d['ms_per_step'],3), 'ms', 'frac', round(d['roofline']['frac'],3), {k: round(v,3) for k,v in d['phases_ms'].items()})
+" || exit 1
+done
