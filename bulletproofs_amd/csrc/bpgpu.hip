@@ -248,7 +248,7 @@ inline Ctx& cx() { return tl_ctx ? *tl_ctx : g_primary; }
 
 // Tuning knobs are process-wide (documented so in bpgpu.h): results never depend on them.
 std::atomic<int> g_window_bits{0};
-std::atomic<size_t> g_freeze_len{1u << 15};  // vectors this short defer the generator fold (0 = never)
+std::atomic<size_t> g_freeze_len{1u << 14};  // vectors this short defer the generator fold (0 = never)
 std::atomic<bool> g_pair_fold{true};         // long rounds fold their generators two rounds at a time (k_fold_joint4)
 std::atomic<size_t> g_ipa_table_min{1u << 12};  // frozen generators at least this many get a fixed-base table (0 = never)
 
@@ -1185,7 +1185,8 @@ int ipa_build_table(bpgpu_ipa* s) {
   if (min_len == 0 || !s->pooled || !s->frozen || s->lazy || s->n0 < min_len || s->n0 < 2) return 0;
   Ctx& C = cx();
   // 18 rows: a scalar at or just below 2^254 (r - 1, say) carries out of window 16 into window 17
-  const int c = TABLE_C, W = (256 + c - 1) / c;
+  static const int dbg_tc = getenv("BPGPU_DBG_TC") ? atoi(getenv("BPGPU_DBG_TC")) : TABLE_C;
+  const int c = dbg_tc, W = (256 + c - 1) / c;
   const uint32_t n0 = (uint32_t)s->n0, stride = 2 * n0 + 1;
   TRY(C.ipa_table.ensure((size_t)W * stride * 64));
   TRY(C.ipa_table_tmp.ensure((size_t)(W - 1) * stride * 96));

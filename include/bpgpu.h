@@ -61,7 +61,7 @@ const char* bpgpu_last_error(void);
  * them, timings do.  MSM window width override (0 = automatic).  */
 int bpgpu_set_window_bits(int c);
 /* IPA sessions whose vectors are at most this long defer the generator fold ("deferred
- * folding"; default 2^15, 0 = always fold).  Tuning only: results are identical either way. */
+ * folding"; default 2^14, 0 = always fold).  Tuning only: results are identical either way. */
 int bpgpu_set_freeze_len(size_t len);
 /* IPA sessions fold the generators of their long rounds two rounds at a time ("pair
  * folding"; default on).  Tuning only: results are identical either way. */
