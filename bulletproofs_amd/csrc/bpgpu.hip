@@ -1176,7 +1176,7 @@ int ipa_freeze(bpgpu_ipa* s) {
   return 0;
 }
 // Fixed-base table for the rounds that are left (the generators are frozen for good at length n0 = s->len).
-// Worth its doubling chain (about 1.5 ms whatever the size: 240 dependent doublings per lane) only when many
+// Worth its doubling chain (0.7 ms at 2^14 generators a side, 1.3 ms at 2^15: 255 dependent doublings per lane) only when many
 // rounds follow, and only the pooled session builds one (the table lives in the context's buffers).
 constexpr int TABLE_C = 15;             // 17 windows of 15 bits = the 255 bits of a Pasta scalar: no sparse top window
 int ipa_build_table(bpgpu_ipa* s) {
@@ -1185,8 +1185,7 @@ int ipa_build_table(bpgpu_ipa* s) {
   if (min_len == 0 || !s->pooled || !s->frozen || s->lazy || s->n0 < min_len || s->n0 < 2) return 0;
   Ctx& C = cx();
   // 18 rows: a scalar at or just below 2^254 (r - 1, say) carries out of window 16 into window 17
-  static const int dbg_tc = getenv("BPGPU_DBG_TC") ? atoi(getenv("BPGPU_DBG_TC")) : TABLE_C;
-  const int c = dbg_tc, W = (256 + c - 1) / c;
+  const int c = TABLE_C, W = (256 + c - 1) / c;
   const uint32_t n0 = (uint32_t)s->n0, stride = 2 * n0 + 1;
   TRY(C.ipa_table.ensure((size_t)W * stride * 64));
   TRY(C.ipa_table_tmp.ensure((size_t)(W - 1) * stride * 96));
