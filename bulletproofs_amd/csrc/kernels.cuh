@@ -631,10 +631,12 @@ __global__ void __launch_bounds__(256) k_reduce1(const uint32_t* __restrict__ bs
 // first (every lane busy), then the wave, then the (up to) four waves of the workgroup through LDS --
 // the addition code is already in the instruction cache here, whereas a separate small kernel for that
 // last step pays more in cold instruction fetches than in arithmetic.  With slices <= 4 the result
-// (ark-form XYZZ) goes to out; otherwise one sum per workgroup goes to tmp and k_reduce3 adds them up.
+// (ark-form XYZZ) goes to out; otherwise one sum per workgroup goes to tmp and either the output's last workgroup
+// (tickets != nullptr) or k_reduce3 adds them up.
 template <int BF>
-__global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tmp,
-                                                 uint32_t* __restrict__ out, uint32_t per, uint32_t slices) {
+__global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* tmp,
+                                                 uint32_t* __restrict__ out, uint32_t per, uint32_t slices,
+                                                 uint32_t* __restrict__ tickets) {
   using E = Ec<BF>;
   using IO = PointIo<BF>;
   __shared__ int32_t xs[4][37];
@@ -686,13 +688,29 @@ __global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ pa
     v.inf = xs[lane][36] != 0;
   }
   v = wave_sum_xyzz<BF, 2>(v);
+  const uint64_t o = (uint64_t)w * gridDim.x + comp;
   if (lane == 0) {
-    const uint64_t o = (uint64_t)w * gridDim.x + comp;
     if (gridDim.z == 1)
       IO::store_ark_xyzz(out + 32ull * o, v);
     else
       IO::store_dev_xyzz(tmp + 32ull * (o * gridDim.z + blockIdx.z), v);
   }
+  if (gridDim.z == 1 || tickets == nullptr) return;
+  // The last workgroup of this output (a ticket per output, zeroed by the host with the sort's counters) adds up the
+  // sums of all gridDim.z (a power of two, at most 64) of them.  Release / acquire by device-scope fences around the
+  // ticket: the other workgroups' stores may sit in another XCD's L2.
+  uint32_t t = 0;
+  if (lane == 0) {
+    __threadfence();
+    t = atomicAdd(&tickets[o], 1u);
+  }
+  t = __builtin_amdgcn_readfirstlane(t);
+  if (t != gridDim.z - 1) return;  // wave-uniform
+  __threadfence();
+  Xyzz a = E::identity();
+  if (lane < gridDim.z) a = IO::load_dev_xyzz(tmp + 32ull * (o * gridDim.z + lane));
+  a = group_sum_xyzz<BF>(a, (int)(gridDim.z >> 1));
+  if (lane == 0) IO::store_ark_xyzz(out + 32ull * o, a);
 }
 
 // out[o] = sum of the `slices` (a power of two, 2..64) slice sums of output o; one lane per slice sum
