@@ -437,7 +437,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const size_t lds_bytes = (size_t)sp.nbins * 4;
   if (lds_bytes > 64 * 1024) return fail(BPGPU_E_ARG, "window width %d needs %zu B of LDS bin counters", c, lds_bytes);
 
-  TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2 + 64 + 256));  // bin_count | chunk counter | tickets | bin_cursor
+  TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2 + 64 + 4096));  // bin_count | chunk counter | tickets | bin_cursor
   TRY(C.cursor.ensure((size_t)(sp.nbins + 1) * 4 * 2));      // bin_start | tile_start
   TRY(C.bcount.ensure((size_t)NB * 4));
   TRY(C.offs.ensure((size_t)(NB + 1) * 4));
@@ -458,8 +458,8 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   uint32_t* d_entries = d_winsum + ws_bytes / 4;
   uint32_t* bin_count = C.counts.as<uint32_t>();
   uint32_t* chunk_counter = bin_count + (size_t)sp.nbins * BIN_PAD;  // zeroed with bin_count
-  uint32_t* red_tickets = chunk_counter + 16;  // k_reduce2: workgroups done per output (64 words, zeroed with bin_count)
-  uint32_t* bin_cursor = red_tickets + 64;
+  uint32_t* red_tickets = chunk_counter + 16;  // k_reduce2: workgroups done per output (1024 words, zeroed with bin_count)
+  uint32_t* bin_cursor = red_tickets + 1024;
   // heavy-bucket lists: at most entries/HEAVY_T heavy buckets and entries/HEAVY_PIECE + that many pieces
   const uint64_t entries = slots * W;
   const uint64_t mean_len = entries / NB;
@@ -493,7 +493,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
 
   hipStream_t st = C.stream;
   HIP_TRY(hipEventRecord(C.ev[0], st));
-  HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4 + 64 + 256, st));
+  HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4 + 64 + 4096, st));
   k_part_count<SF><<<part_grid, 1024, lds_bytes, st>>>(plan, sp, d_scalars, C.canon.as<uint32_t>(), bin_count);
   HIP_TRY(hipEventRecord(C.ev[1], st));
   k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, tile_start, bin_cursor, sp.nbins, d_entries);
@@ -522,7 +522,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     const uint32_t groups = cdiv(slices, 4);  // a workgroup adds up its four slices itself
     // More than one workgroup per output (the prover's short rounds): the last one to finish adds up all of them --
     // its addition code is warm, where a third kernel for two additions spent 39 us on a launch and cold fetches.
-    const bool fused = groups > 1 && groups <= 64 && outputs <= 64;
+    const bool fused = groups > 1 && groups <= 64 && outputs <= 1024;
     TRY(C.redtmp.ensure((size_t)outputs * groups * 128));
     k_reduce2<BF><<<dim3(comps, plan.M * Wb, groups), 256, 0, st>>>(
         C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), d_winsum, runs_per_window, slices, fused ? red_tickets : nullptr);
