@@ -319,14 +319,15 @@ def scalar_kernels_leg(ffi, curve, mad_peak, log2n=24):
     fold_gbs = n * 96 / (best_fold * 1e-3) / 1e9
     ip_gbs = n * 64 / (best_ip * 1e-3) / 1e9
 
-    def valu(mults, ms):
-        # integer ceiling of the same launch: yardstick (136 mads per multiplication) and executed (126) counts
+    def valu(mults, executed, ms):
+        # integer ceiling of the same launch: yardstick (136 mads per multiplication) and the executed multiply-adds
         if not mad_peak:
             return None
         return {"achieved_Tmad_s": n * mults * MADS_PER_FIELD_MUL / (ms * 1e-3) / 1e12, "peak_Tmad_s": mad_peak / 1e12,
                 "frac": n * mults * MADS_PER_FIELD_MUL / (ms * 1e-3) / mad_peak,
-                "frac_executed": n * mults * EXEC_MADS_FIELD_MUL / (ms * 1e-3) / mad_peak}
-    fold_valu, ip_valu = valu(2, best_fold), valu(1, best_ip)
+                "frac_executed": n * executed / (ms * 1e-3) / mad_peak}
+    # the fold's two products share one reduction (Fp::mul_add2): 2 x 81 + 45 multiply-adds
+    fold_valu, ip_valu = valu(2, 2 * 81 + 45, best_fold), valu(1, EXEC_MADS_FIELD_MUL, best_ip)
     return {"bound": "hbm", "kernel": "k_fold_scalars", "achieved": fold_gbs, "peak": peak, "unit": "GB/s",
             "frac": fold_gbs / peak, "traffic": pmc_traffic("k_fold_scalars", True) if (log2n == 24 and curve == 0) else None,
             "traffic_note": f"bytes per launch from the committed rocprofv3 PMC passes ({os.path.basename(PMC_SUMMARY)}, not measured in this "

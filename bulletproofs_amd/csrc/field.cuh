@@ -219,6 +219,30 @@ struct Fp {
     return redc(t);
   }
 
+  // a*b + c*d with one Montgomery reduction; same operand bounds as mul_sub2
+  static BP_MUL Fe mul_add2(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
+    acc_t t[18];
+    BP_UNROLL
+    for (int k = 0; k < 18; k++) t[k] = 0;
+    BP_UNROLL
+    for (int i = 0; i < 9; i++) {
+      BP_UNROLL
+      for (int j = 0; j < 9; j++) {
+        t[i + j] += (acc_t)((int64_t)a.l[i] * (int64_t)b.l[j]);
+        bp_check_acc(t[i + j]);
+      }
+    }
+    BP_UNROLL
+    for (int i = 0; i < 9; i++) {
+      BP_UNROLL
+      for (int j = 0; j < 9; j++) {
+        t[i + j] += (acc_t)((int64_t)c.l[i] * (int64_t)d.l[j]);
+        bp_check_acc(t[i + j]);
+      }
+    }
+    return redc(t);
+  }
+
   static BP_MUL Fe sqr(const Fe& a) {
     acc_t t[18];
     BP_UNROLL

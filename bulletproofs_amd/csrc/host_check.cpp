@@ -47,6 +47,13 @@ static int fe_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     case 10: r = F::is_zero(F::sub(x, y)) ? F::one() : F::zero(); break;
     case 11: r = F::inv_fermat(x); break;
     case 12: r = F::inv(F::sub(F::add(x, x), x)); break;  // lazy (uncarried) operand
+    case 13: {  // a*a' + b*b' with one reduction, operands as the scalar fold has them: unpacked words and products
+      uint32_t pa[8], pb[8];
+      F::pack(F::canon(x), pa);
+      F::pack(F::canon(y), pb);
+      r = F::mul_add2(F::unpack(pa), F::mul(x, y), F::unpack(pb), F::sqr(y));
+      break;
+    }
     default: return -1;
   }
   F::store_ark(r, wo);

@@ -952,7 +952,7 @@ __global__ void __launch_bounds__(256) k_fold_scalars(uint32_t* __restrict__ v0,
     uint4 l0 = pl[0], l1 = pl[1], h0 = ph[0], h1 = ph[1];
     uint32_t wl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
     uint32_t wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    Fe r = F::add(F::mul(F::unpack(wl), slo), F::mul(F::unpack(wh), shi));
+    Fe r = F::mul_add2(F::unpack(wl), slo, F::unpack(wh), shi);  // one reduction for the two products
     uint32_t w[8];
     F::store_packed(r, w);
     uint4* po = reinterpret_cast<uint4*>(o + 8ull * i);

@@ -66,6 +66,7 @@ def test_field_ops(chk, fid):
         assert fe_op(chk, fid, 7, a, b) == (b - a) * (a - b) % p
         assert fe_op(chk, fid, 8, a, b) == (-a) % p
         assert fe_op(chk, fid, 10, a, b) == (1 if a == b else 0)
+        assert fe_op(chk, fid, 13, a, b) == (a * (a * b) + b * (b * b)) % p     # mul_add2: two products, one reduction
     for a in vals:
         if a:
             assert fe_op(chk, fid, 4, a, 0) == pow(a, -1, p)
