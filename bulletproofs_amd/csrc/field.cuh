@@ -299,6 +299,17 @@ struct Fp {
     return r;
   }
 
+  // canonical representative of a value known to lie in (-p, p): one conditional addition of p
+  // (a product of a < 2^256 and a canonical b leaves redc in (-p, p/32]; sums of two such in (-p, p/16])
+  static BP_HD Fe canon_small(const Fe& a) {
+    Fe r = carry(a);
+    const int32_t neg = r.l[8] >> 31;  // all ones iff negative
+    BP_UNROLL
+    for (int i = 0; i < 9; i++)
+      if (C::P29[i] != 0) r.l[i] += (int32_t)C::P29[i] & neg;
+    return carry(r);
+  }
+
   // exact test  value == 0 (mod p)  for |value| < 128p
   static BP_HD bool is_zero(const Fe& a) {
     // k*p mod 2^29 = k mod 2^29 with |k| <= 128: cheap filter on the low limb

@@ -54,6 +54,25 @@ static int fe_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
       r = F::mul_add2(F::unpack(pa), F::mul(x, y), F::unpack(pb), F::sqr(y));
       break;
     }
+    case 14: {  // the scalar fold's output path: packed words times canonical multipliers, conditional-add canonicalisation
+      uint32_t pa[8], pb[8];
+      F::pack(F::canon(x), pa);
+      F::pack(F::canon(y), pb);
+      r = F::canon_small(F::mul_add2(F::unpack(pa), F::canon(F::mul(x, y)), F::unpack(pb), F::canon(F::sqr(y))));
+      Fe full = F::canon(r);
+      for (int i = 0; i < 9; i++)
+        if (full.l[i] != r.l[i]) bp_check_fail("canon_small is not canonical");
+      break;
+    }
+    case 15: {  // ark form -> canonical integer as the digit kernel does it (output: that integer, as ark words of it / 2^256)
+      Fe v = F::canon_small(F::mul(F::unpack(wa), F::from_const(F::C::C256TOCANON)));
+      Fe full = F::canon(v);
+      for (int i = 0; i < 9; i++)
+        if (full.l[i] != v.l[i]) bp_check_fail("canon_small is not canonical");
+      F::pack(v, wo);
+      for (int i = 0; i < 8; i++) out[i] = wo[i];
+      return 0;
+    }
     default: return -1;
   }
   F::store_ark(r, wo);

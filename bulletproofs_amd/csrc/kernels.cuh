@@ -140,8 +140,9 @@ __global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, 
     const uint4* sp4 = reinterpret_cast<const uint4*>(scalars + 8ull * sc_idx);
     uint4 lo = sp4[0], hi = sp4[1];
     uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    // words < 2^256 times the plain constant 32: the reduced value lies in (-p, 1], one conditional addition away
     Fe v = F::mul(F::unpack(w), F::from_const(F::C::C256TOCANON));
-    F::pack(F::canon(v), w);
+    F::pack(F::canon_small(v), w);
     uint32_t carry = 0;
     // bucket set of window j: m W + j, or m alone in table mode (all windows share one set)
     const uint32_t wb0 = plan.table_stride ? (uint32_t)m : (uint32_t)(m * W), wbs = plan.table_stride ? 0u : 1u;
@@ -937,13 +938,14 @@ __global__ void __launch_bounds__(256) k_fold_scalars(uint32_t* __restrict__ v0,
   const uint32_t* v = blockIdx.y == 0 ? v0 : v1;
   uint32_t* o = blockIdx.y == 0 ? o0 : o1;
   // device form of the two multipliers, once per lane: montmul(v 2^256, s 2^261) = vs 2^256, ark form again
+  // (canonical: the products' sum then lies in (-p, p/16] and one conditional addition canonicalises it)
   Fe slo, shi;
   if (blockIdx.y == 0) {
-    slo = F::load_ark(s0.lo);
-    shi = F::load_ark(s0.hi);
+    slo = F::canon(F::load_ark(s0.lo));
+    shi = F::canon(F::load_ark(s0.hi));
   } else {
-    slo = F::load_ark(s1.lo);
-    shi = F::load_ark(s1.hi);
+    slo = F::canon(F::load_ark(s1.lo));
+    shi = F::canon(F::load_ark(s1.hi));
   }
   // `o` may alias `v`: every output reads only its own two inputs before it is written
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -954,7 +956,7 @@ __global__ void __launch_bounds__(256) k_fold_scalars(uint32_t* __restrict__ v0,
     uint32_t wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
     Fe r = F::mul_add2(F::unpack(wl), slo, F::unpack(wh), shi);  // one reduction for the two products
     uint32_t w[8];
-    F::store_packed(r, w);
+    F::pack(F::canon_small(r), w);
     uint4* po = reinterpret_cast<uint4*>(o + 8ull * i);
     po[0] = make_uint4(w[0], w[1], w[2], w[3]);
     po[1] = make_uint4(w[4], w[5], w[6], w[7]);

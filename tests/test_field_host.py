@@ -67,6 +67,7 @@ def test_field_ops(chk, fid):
         assert fe_op(chk, fid, 8, a, b) == (-a) % p
         assert fe_op(chk, fid, 10, a, b) == (1 if a == b else 0)
         assert fe_op(chk, fid, 13, a, b) == (a * (a * b) + b * (b * b)) % p     # mul_add2: two products, one reduction
+        assert fe_op(chk, fid, 14, a, b) == (a * (a * b) + b * (b * b)) % p     # ... and canon_small on the result
     for a in vals:
         if a:
             assert fe_op(chk, fid, 4, a, 0) == pow(a, -1, p)
@@ -83,6 +84,12 @@ def test_field_ops(chk, fid):
             assert fe_op(chk, fid, 4, a, 0) == pow(a, -1, p), hex(a)
     for a, b in pairs[:50]:
         assert fe_op(chk, fid, 9, a, b) == (a + 20 * (a + b)) * b % p
+    # ark words (any 256-bit pattern, canonical or not) -> canonical integer, the digit kernel's conversion
+    for raw in [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p, 3 * p + 5, (1 << 256) - 1, (1 << 255), R256 % p] + [rnd.getrandbits(256) for _ in range(300)]:
+        wa = np.frombuffer(raw.to_bytes(32, "little"), dtype=np.uint32).copy()
+        wo = np.zeros(8, dtype=np.uint32)
+        assert chk.bpchk_fe_op(fid, 15, wa.ctypes.data, wa.ctypes.data, wo.ctypes.data) == 0
+        assert int.from_bytes(wo.tobytes(), "little") == raw * pow(R256, -1, p) % p, hex(raw)
     assert chk.bpchk_failures() == 0, "an int64 accumulator / int32 limb bound was violated"
 
 
