@@ -335,9 +335,9 @@ def scalar_kernels_leg(ffi, curve, mad_peak, log2n=24):
             "avg_kernel_ms": best_fold,
             "outputs": n, "algorithmic_bytes_per_output": 96,
             "valu_ceiling": fold_valu,
-            "binds": "both: the kernel issues ~580 VALU instructions per output (unpack, two multiplications, canonical "
-                     "reduction, pack), so VALU issue time is within 15 % of the HBM time (profiles/, PMC SQ_INSTS_VALU); HBM is "
-                     "the higher of the two fractions",
+            "binds": "hbm: the kernel issues ~360 VALU instructions per output (unpack, two products with one reduction, "
+                     "conditional-add canonicalisation, pack: profiles/, PMC SQ_INSTS_VALU), 0.17 ms of issue time against a "
+                     "0.31-0.32 ms kernel; it was co-bound at ~580 instructions per output before the products shared a reduction",
             "k_ip": {"achieved": ip_gbs, "frac": ip_gbs / peak, "kernel_ms": best_ip, "terms": n,
                      "algorithmic_bytes_per_term": 64, "valu_ceiling": ip_valu, "binds": "hbm"}}
 
