@@ -1320,8 +1320,8 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
 //     = (x0 x1)^-1 [ A_i + x1^2 A_{i+q} + x0^2 A_{i+2q} + x0^2 x1^2 A_{i+3q} ].
 // The three shared multipliers ride ONE doubling chain (128 doublings for three multiplications
 // instead of 3 x 128 when the rounds fold one after the other); digits are Eisenstein units as in
-// k_fold_monic, the unit's x is formed on the fly (one multiplication by zeta or zeta^2) to keep
-// the three points in registers.  out may alias g: a lane reads only indices = i (mod q).
+// k_fold_monic; zeta x of the three generators is kept in registers, a unit's x of the Q' orbit is formed on the
+// fly (one multiplication by zeta or zeta^2).  out may alias g: a lane reads only indices = i (mod q).
 // ---------------------------------------------------------------------------
 struct Joint4Plan {
   MonicPlan m[3];  // multipliers of g[i+q], g[i+2q], g[i+3q]
@@ -1375,6 +1375,9 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
   }
   Jac acc = E::jidentity();  // Jacobian: the chain is mostly doublings
   if (active) {
+    // zeta x of the three generators stays in registers: their unit digits then need no multiplication
+    // (zeta^2 x = -(x + zeta x), since 1 + zeta + zeta^2 = 0); the digits of Q' (in LDS) still form theirs on the fly
+    const Fe zx0 = F::mul(Q0.x, zeta), zx1 = F::mul(Q1.x, zeta), zx2 = F::mul(Q2.x, zeta);
     for (int pos = f->len - 1; pos >= 0; pos--) {
       acc = E::jdbl(acc);
 #pragma unroll 1
@@ -1390,11 +1393,15 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
               p.x.l[k] = qa[18 * t + k][tid];
               p.y.l[k] = qa[18 * t + 9 + k][tid];
             }
+            if (sel != 1) p.x = F::mul(p.x, sel == 2 ? zeta : zeta2);
           } else {
             p.x = t == 0 ? Q0.x : (t == 1 ? Q1.x : Q2.x);
             p.y = t == 0 ? Q0.y : (t == 1 ? Q1.y : Q2.y);
+            if (sel != 1) {
+              const Fe zx = t == 0 ? zx0 : (t == 1 ? zx1 : zx2);
+              p.x = sel == 2 ? zx : F::carry(F::neg(F::add(p.x, zx)));
+            }
           }
-          if (sel != 1) p.x = F::mul(p.x, sel == 2 ? zeta : zeta2);
           if (code & 8u) p.y = F::carry(F::neg(p.y));
           E::jmadd(acc, p);  // skips an identity operand (zero padding)
         }
