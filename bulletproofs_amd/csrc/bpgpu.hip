@@ -1114,9 +1114,16 @@ int fold_joint4_launch(int curve, uint32_t* gA, const uint64_t sA[3][4], uint32_
     for (int t = 0; t < 3; t++) adds += count_codes(plans.p[v].m[t].codes, plans.p[v].m[t].len);
     C.fold_ops[2] += (uint64_t)q * adds;
   }
-  dim3 grid(cdiv(q, 256), 2);
+  // short vectors: two lanes an output (half of the chain's additions each) while that still leaves a wave a SIMD
+  const bool split = (uint64_t)q * 2 * 2 <= (uint64_t)C.num_cus * 256;
+  dim3 grid(split ? cdiv(q, 128) : cdiv(q, 256), 2);
   HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
-  if (curve == BPGPU_PALLAS)
+  if (split) {
+    if (curve == BPGPU_PALLAS)
+      k_fold_joint4_split<0><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);
+    else
+      k_fold_joint4_split<1><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);
+  } else if (curve == BPGPU_PALLAS)
     k_fold_joint4<0><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);
   else
     k_fold_joint4<1><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);

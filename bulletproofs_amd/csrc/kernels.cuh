@@ -1414,6 +1414,121 @@ __global__ void __launch_bounds__(256) k_fold_joint4(const uint32_t* g0, uint32_
   if (active) IO::store_dev_affine(o + 16ull * i, E::jto_affine_with(acc, inv));
 }
 
+// The same fold for short vectors (q <= 2^14: fewer outputs than the chip has SIMDs x 64 lanes, so the kernel above
+// is one long chain of 128 doublings and 165 additions per lane with half the SIMDs idle, and a lone wave runs no
+// slower than one that shares its SIMD).  Here two lanes share an output: both walk the doubling chain, lane 0 with
+// the digits of s1 and the even positions of s2 (and P at the end), lane 1 with those of s3 and the odd positions of
+// s2 -- any split of the (position, multiplier) pairs is a valid split of the sum, and this one is uniform per wave
+// (waves 0-1 of a workgroup are lane 0 of 128 outputs, waves 2-3 lane 1).  83 additions a lane instead of 165; the
+// two halves meet in LDS (as XYZZ: Ec::add is the tested general addition) and lane 0 normalises through the
+// workgroup-shared inversion.  Twice the doublings in all, 0.7 of the latency where latency is all there is.
+// (Three lanes an output, one per multiplier, gain nothing at q = 2^14: 1536 waves on 1024 SIMDs.)
+template <int BF>
+__global__ void __launch_bounds__(256) k_fold_joint4_split(const uint32_t* g0, uint32_t* o0, const uint32_t* g1, uint32_t* o1,
+                                                           const Plans2<Joint4Plan> plans, uint32_t q) {
+  using F = Fp<BF>;
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  __shared__ uint32_t tree[512][9];
+  __shared__ int32_t xch[37][128];  // XYZZ results of the second lanes (36 limbs + identity flag)
+  const uint32_t tid = threadIdx.x, col = tid & 127u, role = tid >> 7;
+  const uint32_t i = blockIdx.x * 128 + col;
+  const bool active = i < q;
+  const uint32_t* g = blockIdx.y == 0 ? g0 : g1;
+  uint32_t* o = blockIdx.y == 0 ? o0 : o1;
+  const Joint4Plan* f = &plans.p[blockIdx.y];
+  const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
+  // generator a: all digits of multiplier ta; generator b = Q_2 (multiplier index 1): the positions of parity `role`
+  const int ta = role == 0 ? 0 : 2;
+  Aff Qa, Qb;
+  Qa.inf = Qb.inf = true;
+  if (active) {
+    Qa = IO::load_dev_affine(g + 16ull * (i + (uint64_t)(ta + 1) * q));
+    Qb = IO::load_dev_affine(g + 16ull * (i + 2ull * q));
+  }
+  Aff Aa, Ab;  // alpha Q
+  Aa.inf = Qa.inf;
+  Ab.inf = Qb.inf;
+  {
+    const Fe da = Qa.inf ? F::one() : alpha_den<BF>(Qa, zeta), db = Qb.inf ? F::one() : alpha_den<BF>(Qb, zeta);
+    const Fe iv = block_inverse_256<BF>(F::mul(da, db), tree);
+    const Fe zeta2 = F::sqr(zeta);
+    Aa = Qa.inf ? Qa : alpha_point<BF>(Qa, F::mul(iv, db), zeta2);
+    Ab = Qb.inf ? Qb : alpha_point<BF>(Qb, F::mul(iv, da), zeta2);
+  }
+  Jac acc = E::jidentity();
+  if (active) {
+    const Fe zxa = F::mul(Qa.x, zeta), zaa = F::mul(Aa.x, zeta), zxb = F::mul(Qb.x, zeta), zab = F::mul(Ab.x, zeta);
+    for (int pos = f->len - 1; pos >= 0; pos--) {
+      acc = E::jdbl(acc);
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {  // h = 0: generator a, h = 1: generator b
+        if (h == 1 && (uint32_t)(pos & 1) != role) continue;  // wave-uniform
+        const MonicPlan* m = &f->m[h == 0 ? ta : 1];
+        const uint32_t code = pos < m->len ? (m->codes[pos >> 3] >> ((pos & 7) * 4)) & 15u : 0u;
+        const uint32_t sel = code & 3u;
+        if (!sel) continue;
+        const bool alt = (code & 4u) != 0;  // a digit of the alpha orbit
+        Aff p;
+        p.inf = h == 0 ? Qa.inf : Qb.inf;
+        p.x = h == 0 ? (alt ? Aa.x : Qa.x) : (alt ? Ab.x : Qb.x);
+        p.y = h == 0 ? (alt ? Aa.y : Qa.y) : (alt ? Ab.y : Qb.y);
+        if (sel != 1) {
+          const Fe z1 = h == 0 ? (alt ? zaa : zxa) : (alt ? zab : zxb);
+          p.x = sel == 2 ? z1 : F::carry(F::neg(F::add(p.x, z1)));  // zeta^2 x = -(x + zeta x)
+        }
+        if (code & 8u) p.y = F::carry(F::neg(p.y));
+        E::jmadd(acc, p);  // skips an identity operand (zero padding)
+      }
+    }
+    if (role == 0) E::jmadd(acc, IO::load_dev_affine(g + 16ull * i));
+  }
+  Xyzz r = E::identity();
+  if (active && !acc.inf) {
+    r.x = acc.x;
+    r.y = acc.y;
+    r.zz = F::sqr(acc.z);
+    r.zzz = F::mul(r.zz, acc.z);
+    r.inf = false;
+  }
+  if (role == 1) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      xch[k][col] = r.x.l[k];
+      xch[9 + k][col] = r.y.l[k];
+      xch[18 + k][col] = r.zz.l[k];
+      xch[27 + k][col] = r.zzz.l[k];
+    }
+    xch[36][col] = r.inf ? 1 : 0;
+  }
+  __syncthreads();
+  if (role == 0) {
+    Xyzz b;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      b.x.l[k] = xch[k][col];
+      b.y.l[k] = xch[9 + k][col];
+      b.zz.l[k] = xch[18 + k][col];
+      b.zzz.l[k] = xch[27 + k][col];
+    }
+    b.inf = xch[36][col] != 0;
+    r = E::add(r, b);
+  }
+  const bool fin = role == 0 && active && !r.inf;
+  const Fe inv = block_inverse_256<BF>(fin ? F::mul(r.zz, r.zzz) : F::one(), tree);
+  if (role == 0 && active) {
+    Aff a;
+    a.inf = !fin;
+    a.x = F::zero();
+    a.y = F::zero();
+    if (fin) {
+      a.x = F::mul(r.x, F::mul(inv, r.zzz));
+      a.y = F::mul(r.y, F::mul(inv, r.zz));
+    }
+    IO::store_dev_affine(o + 16ull * i, a);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Fixed-base table of the prover's frozen generators (MsmPlan::table_stride).  The short rounds of a proof run
 // fifteen pairs of MSMs over the SAME points; with the multiples 2^(c w) P at hand every window's digits share
