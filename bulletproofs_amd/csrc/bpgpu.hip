@@ -467,7 +467,11 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   // The floor follows the work there is per lane: in a small MSM (the prover's short rounds) one list of 127
   // entries -- the top window's carry-only bucket -- kept a lane busy for 0.45 ms, longer than the rest of
   // the kernel (tools/msm_var_probe.py: 0.18 vs 0.54 ms depending on which side of 128 that bucket fell).
-  const uint64_t lanes = (uint64_t)C.num_cus * 4 * BP_ACCUM_WAVES * 64;
+  // table mode (the prover's short rounds) is a chain of latencies, not of throughput: a wave that has its SIMD to
+  // itself issues an instruction every 5 clocks, one that shares it every 8 -- one persistent wave per SIMD there
+  // (accumulation 0.116 -> 0.092 ms), two everywhere else
+  const int accum_waves = table ? 1 : BP_ACCUM_WAVES;
+  const uint64_t lanes = (uint64_t)C.num_cus * 4 * accum_waves * 64;
   uint64_t floor_t = 4 * entries / lanes;
   if (floor_t < 32) floor_t = 32;
   if (floor_t > HEAVY_T_MIN) floor_t = HEAVY_T_MIN;
@@ -507,7 +511,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   k_bin_place<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
                                           C.offs.as<uint32_t>(), C.bcount.as<uint32_t>(), C.sorted.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[3], st));
-  k_accum<BF><<<C.num_cus * BP_ACCUM_WAVES, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
+  k_accum<BF><<<C.num_cus * accum_waves, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
                                              C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits, hv,
                                              chunk_counter, glog);
   k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
