@@ -388,8 +388,12 @@ int choose_window(uint32_t n, int M) {
 
 // Batched MSM over device-resident operands.  d_points: dev affine; d_scalars: ark form.
 // out[m] receives xy_inf.
+// points_ready (optional): called once the sort has been launched and before the accumulation is; it must put whatever
+// makes d_points valid onto the context's stream (the host-buffer entry points upload the points there: the sort needs
+// the scalars only, so it runs while the points are still crossing PCIe).
 template <int CURVE>
-int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, uint64_t (*out)[9]) {
+int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, uint64_t (*out)[9],
+             const std::function<int()>* points_ready = nullptr) {
   constexpr int BF = CURVE, SF = 1 - CURVE;
   Ctx& C = cx();
   for (int m = 0; m < plan.M; m++) {
@@ -510,6 +514,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
                                            C.order.as<uint32_t>(), hv);
   k_bin_place<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
                                           C.offs.as<uint32_t>(), C.bcount.as<uint32_t>(), C.sorted.as<uint32_t>());
+  if (points_ready) TRY((*points_ready)());
   HIP_TRY(hipEventRecord(C.ev[3], st));
   k_accum<BF><<<C.num_cus * accum_waves, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
                                              C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits, hv,
@@ -584,9 +589,9 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
 }
 
 int msm_dispatch(int curve, const uint32_t* d_points, const uint32_t* d_scalars, const MsmPlan& plan,
-                 uint64_t (*out)[9]) {
-  return curve == BPGPU_PALLAS ? msm_core<0>(d_points, d_scalars, plan, out)
-                               : msm_core<1>(d_points, d_scalars, plan, out);
+                 uint64_t (*out)[9], const std::function<int()>* points_ready = nullptr) {
+  return curve == BPGPU_PALLAS ? msm_core<0>(d_points, d_scalars, plan, out, points_ready)
+                               : msm_core<1>(d_points, d_scalars, plan, out, points_ready);
 }
 
 MsmPlan single_plan(uint32_t n) {
@@ -1446,12 +1451,17 @@ static int msm_host(int curve, const uint64_t* points, int fmt, const uint64_t* 
     TRY(cx().st_pts_in.ensure(pbytes));
     TRY(cx().st_pts.ensure(n * 64));
     TRY(cx().st_sc.ensure(n * 32));
-    HIP_TRY(upload_async(cx().st_pts_in.p, points, pbytes, cx().stream));
     HIP_TRY(upload_async(cx().st_sc.p, scalars, n * 32, cx().stream));
-    TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), cx().st_pts.as<uint32_t>(), n, fmt));
   }
+  // scalars first: the sort runs on them while the (three times larger) points are uploaded and converted
+  const std::function<int()> points_ready = [&]() -> int {
+    if (!n) return 0;
+    const size_t pbytes = n * (fmt == 0 ? 96 : 64);
+    HIP_TRY(upload_async(cx().st_pts_in.p, points, pbytes, cx().stream));
+    return points_in(curve, cx().st_pts_in.as<uint32_t>(), cx().st_pts.as<uint32_t>(), n, fmt);
+  };
   return msm_dispatch(curve, cx().st_pts.as<uint32_t>(), cx().st_sc.as<uint32_t>(), single_plan((uint32_t)n),
-                      (uint64_t(*)[9])out_xy_inf);
+                      (uint64_t(*)[9])out_xy_inf, &points_ready);
 }
 
 int bpgpu_msm(int curve, const uint64_t* points_xyz, const uint64_t* scalars, size_t n, uint64_t out_xy_inf[9]) {
