@@ -531,12 +531,12 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     const uint32_t groups = cdiv(slices, 4);  // a workgroup adds up its four slices itself
     // More than one workgroup per output (the prover's short rounds): the last one to finish adds up all of them --
     // its addition code is warm, where a third kernel for two additions spent 39 us on a launch and cold fetches.
-    const bool fused = groups > 1 && groups <= 64 && outputs <= 1024;
+    // (more than four slices only happen with at most 64 outputs: the loop above keeps slices x outputs <= 1024)
+    const bool fused = groups > 1;
+    if (fused && (groups > 64 || outputs > 1024)) return fail(BPGPU_E_STATE, "reduction: %u outputs in %u groups", outputs, groups);
     TRY(C.redtmp.ensure((size_t)outputs * groups * 128));
     k_reduce2<BF><<<dim3(comps, plan.M * Wb, groups), 256, 0, st>>>(
         C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), d_winsum, runs_per_window, slices, fused ? red_tickets : nullptr);
-    if (groups > 1 && !fused)
-      k_reduce3<BF><<<cdiv(outputs * groups, 256), 256, 0, st>>>(C.redtmp.as<uint32_t>(), d_winsum, outputs, groups);
   }
   HIP_TRY(hipEventRecord(C.ev[5], st));
   // Horner tail on four host threads (three pool workers and this one): a batch of two MSMs gives each MSM

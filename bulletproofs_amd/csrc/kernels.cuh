@@ -632,8 +632,8 @@ __global__ void __launch_bounds__(256) k_reduce1(const uint32_t* __restrict__ bs
 // first (every lane busy), then the wave, then the (up to) four waves of the workgroup through LDS --
 // the addition code is already in the instruction cache here, whereas a separate small kernel for that
 // last step pays more in cold instruction fetches than in arithmetic.  With slices <= 4 the result
-// (ark-form XYZZ) goes to out; otherwise one sum per workgroup goes to tmp and either the output's last workgroup
-// (tickets != nullptr) or k_reduce3 adds them up.
+// (ark-form XYZZ) goes to out; otherwise one sum per workgroup goes to tmp and the output's last workgroup adds them
+// up (tickets).
 template <int BF>
 __global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ partial, uint32_t* tmp,
                                                  uint32_t* __restrict__ out, uint32_t per, uint32_t slices,
@@ -712,32 +712,6 @@ __global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ pa
   if (lane < gridDim.z) a = IO::load_dev_xyzz(tmp + 32ull * (o * gridDim.z + lane));
   a = group_sum_xyzz<BF>(a, (int)(gridDim.z >> 1));
   if (lane == 0) IO::store_ark_xyzz(out + 32ull * o, a);
-}
-
-// out[o] = sum of the `slices` (a power of two, 2..64) slice sums of output o; one lane per slice sum
-template <int BF>
-__global__ void __launch_bounds__(256) k_reduce3(const uint32_t* __restrict__ tmp, uint32_t* __restrict__ out,
-                                                 uint32_t outputs, uint32_t slices) {
-  using E = Ec<BF>;
-  using IO = PointIo<BF>;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t o = t / slices;
-  Xyzz acc = E::identity();
-  if (o < outputs) acc = IO::load_dev_xyzz(tmp + 32ull * t);
-#pragma unroll 1
-  for (uint32_t off = slices >> 1; off >= 1; off >>= 1) {
-    Xyzz v;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      v.x.l[i] = __shfl_down(acc.x.l[i], off, 64);
-      v.y.l[i] = __shfl_down(acc.y.l[i], off, 64);
-      v.zz.l[i] = __shfl_down(acc.zz.l[i], off, 64);
-      v.zzz.l[i] = __shfl_down(acc.zzz.l[i], off, 64);
-    }
-    v.inf = __shfl_down((int)acc.inf, off, 64) != 0;
-    acc = E::add(acc, v);
-  }
-  if (o < outputs && (t & (slices - 1)) == 0) IO::store_ark_xyzz(out + 32ull * o, acc);
 }
 
 // ---------------------------------------------------------------------------

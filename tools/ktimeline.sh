@@ -18,5 +18,5 @@ for r in rows[idx:]:
     n = r["Kernel_Name"].split("(")[0].replace("void bpgpu::", "")
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     print(f'{n[:28]:28s} q{r.get("Queue_Id","?"):>3s} start {s/1e3:9.1f} us  end {e/1e3:9.1f} us  dur {(e-s)/1e3:8.1f}')
-    if "k_reduce2" in n or "k_reduce3" in n: break
+    if "k_reduce2" in n: break
 PY
