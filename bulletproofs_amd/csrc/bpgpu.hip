@@ -424,6 +424,9 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   // once the second stage's share is large (profiles/r01_window_sweep.txt, second table)
   int s = c - 1 < 3 ? c - 1 : 3;
   if (NB >= (800u << 10) && c - 1 >= 4) s = 4;
+  // two million buckets and more (a batch of two 2^20-slot MSMs): runs of 32 put the first stage on one wave per SIMD
+  // again and halve the second stage's lists (reduce 0.73 -> 0.66 ms); no difference at 2^24, slower below
+  if (NB >= (1600u << 10) && c - 1 >= 5) s = 5;
   if (c - 1 - s > 13) s = c - 1 - 13;
   if (table && c - 1 >= 2) s = 2;  // few buckets: the reduction is a chain of additions, keep it short
   const uint32_t nruns = NB >> s;
