@@ -2362,7 +2362,10 @@ int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv
     IPA_TRY(ipa_freeze(s));
     IPA_TRY(ipa_build_table(s));
   }
-  IPA_HIP_TRY(hipStreamSynchronize(cx().stream));
+  // With frozen generators the round's device work is two small kernels (and once the table build): the call returns
+  // without waiting for them -- the next round_lr / finish / export waits on the same stream and reports their errors
+  // (a wait here costs a short round 20 us of wake-up latency, and the caller's Fiat-Shamir hop overlaps the table build)
+  if (!s->frozen) IPA_HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
 

@@ -220,6 +220,9 @@ int bpgpu_ipa_begin_device(int curve, const void* d_a_gens, const void* d_b_gens
 /* current (padded) vector length; 1 when the loop is finished */
 size_t bpgpu_ipa_len(const bpgpu_ipa* s);
 int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9]);
+/* round_fold copies x and x_inv before it returns.  Once the session's generators are frozen (short vectors) it
+ * returns without waiting for its device work: a device error of that work is reported by the next call on the
+ * session that waits (round_lr, finish, export), which then marks the session failed like any other error. */
 int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv[4]);
 int bpgpu_ipa_finish(bpgpu_ipa* s, uint64_t final_a[4], uint64_t final_b[4]);
 int bpgpu_ipa_export(bpgpu_ipa* s, uint64_t* a_gens_xyz, uint64_t* b_gens_xyz, uint64_t* a,
