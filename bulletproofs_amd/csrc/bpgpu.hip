@@ -100,22 +100,36 @@ struct PinnedBuf {
 class Pool {
  public:
   ~Pool() { stop(); }
+  // A pool may be started again after stop() (bpgpu_shutdown followed by bpgpu_init): the generation counter
+  // survives, so every new worker starts from the CURRENT generation -- it must never run the job of an
+  // earlier run, whose captures point into a frame that is gone -- and the job is dropped once its run ends.
   void start(int n) {
     if (!th_.empty()) return;
-    quit_ = false;
-    n_ = n;
+    uint64_t gen0;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = false;
+      n_ = n;
+      pending_ = 0;
+      job_ = nullptr;
+      gen0 = gen_;
+    }
     for (int w = 0; w < n; w++)
-      th_.emplace_back([this, w] {
-        uint64_t seen = 0;
+      th_.emplace_back([this, w, gen0] {
+        uint64_t seen = gen0;
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
           cv_.wait(lk, [&] { return quit_ || gen_ != seen; });
           if (quit_) return;
           seen = gen_;
+          const std::function<void(int)>* job = &job_;  // stays valid until pending_ reaches 0
           lk.unlock();
-          job_(w);
+          (*job)(w);
           lk.lock();
-          if (--pending_ == 0) done_.notify_all();
+          if (--pending_ == 0) {
+            job_ = nullptr;
+            done_.notify_all();
+          }
         }
       });
   }
@@ -128,6 +142,9 @@ class Pool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
     th_.clear();
+    std::lock_guard<std::mutex> lk(mu_);
+    pending_ = 0;
+    job_ = nullptr;
   }
   int size() const { return n_; }
   // one run at a time (callers hold the owning context's mutex, or the registry's for the shard pool).
@@ -158,13 +175,39 @@ class Pool {
   bool quit_ = false;
 };
 
+// Host threads a context may keep beside its caller (Horner workers, staging threads): three where the host has
+// the cores, fewer when many contexts (bpgpu_sharded_init) or many processes (one rank per GPU: LOCAL_WORLD_SIZE,
+// set by torch.distributed.run) share it -- max(1, min(3, cores / (2 P))), P = contexts on this host.  The core
+// count is BPGPU_HOST_CORES when set (a container's CPU share is not what the OS reports), else what the OS reports.
+std::atomic<int> g_ctx_count{1};  // contexts of this process (primary + shards), for the budget
+int helper_threads() {
+  long cores = (long)std::thread::hardware_concurrency();
+  if (const char* e = getenv("BPGPU_HOST_CORES")) {
+    const long v = atol(e);
+    if (v > 0) cores = v;
+  }
+  if (cores < 1) cores = 1;
+  long procs = 1;
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) {
+    const long v = atol(e);
+    if (v > 0) procs = v;
+  }
+  long P = (long)g_ctx_count.load() * procs;
+  if (P < 1) P = 1;
+  long t = cores / (2 * P);
+  if (t > 3) t = 3;
+  if (t < 1) t = 1;
+  return (int)t;
+}
+
 // Large host-to-device copies.  hipMemcpyAsync from pageable memory moves 29 GB/s on the MI355X box, from
 // pinned memory 57 GB/s (tools/h2d_probe.py), and one host core copies 32 GB/s: three persistent worker
 // threads stage 4 MiB chunks into pinned buffers, each chunk's DMA following on the worker's own stream.
 struct Uploader {
-  static constexpr int T = 3, SLOTS = 2;
+  static constexpr int T = 3, SLOTS = 2;  // T: the most staging threads; nt of them run (helper_threads())
   static constexpr size_t CH = 4u << 20, MIN_BYTES = 8u << 20;
   bool ready = false;
+  int nt = T;
   void* buf[T][SLOTS] = {};
   hipStream_t ws[T] = {};
   hipEvent_t ev[T][SLOTS] = {};
@@ -172,8 +215,9 @@ struct Uploader {
   Pool pool;
   hipError_t init() {
     if (ready) return hipSuccess;
+    nt = helper_threads();
     hipError_t e = hipEventCreateWithFlags(&fence, hipEventDisableTiming);
-    for (int w = 0; w < T && e == hipSuccess; w++) {
+    for (int w = 0; w < nt && e == hipSuccess; w++) {
       e = hipStreamCreateWithFlags(&ws[w], hipStreamNonBlocking);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&done[w], hipEventDisableTiming);
       for (int k = 0; k < SLOTS && e == hipSuccess; k++) {
@@ -181,8 +225,9 @@ struct Uploader {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[w][k], hipEventDisableTiming);
       }
     }
-    if (e == hipSuccess) pool.start(T);
+    if (e == hipSuccess) pool.start(nt);
     ready = e == hipSuccess;
+    if (!ready) release();  // a half-built uploader keeps nothing
     return e;
   }
   void release() {
@@ -229,7 +274,7 @@ struct Ctx {
   // staging for host-buffer entry points
   DevBuf st_pts_in, st_pts, st_sc, st_out, st_ip;
   DevBuf aux[6];  // sparse products (row pointers, indices, permutation, values, vector, result), point sampling
-  Pool hpool;  // three host threads that share the Horner tail with the caller's thread
+  Pool hpool;  // up to three host threads (helper_threads()) that share the Horner tail with the caller's thread
   PinnedBuf h_winsum;  // window sums land here (pinned: the copy is a plain DMA)
   Uploader up;
   // the buffers of the last closed IPA session, kept for the next one (a prover makes proof after proof of
@@ -242,15 +287,21 @@ struct Ctx {
 Ctx g_primary;                              // bpgpu_init
 std::vector<std::unique_ptr<Ctx>> g_shards;  // bpgpu_sharded_init, one per (logical) GPU of the sharded MSM
 Pool g_shard_pool;                          // one persistent host thread per shard context
-std::mutex g_reg_mu;                        // shard registry and sharded calls (one sharded MSM at a time)
+// One sharded call at a time is the contract: the legs of a call occupy every shard context and the one shard pool
+// (a second call could only queue behind them), so g_shard_run_mu is held for the whole call -- and by
+// bpgpu_sharded_init / bpgpu_shutdown, which therefore wait for a running call.  g_reg_mu only guards the vector
+// itself and is never held across device work (bpgpu_sharded_count does not wait for an MSM).
+std::mutex g_shard_run_mu;
+std::mutex g_reg_mu;
 thread_local Ctx* tl_ctx = nullptr;
 inline Ctx& cx() { return tl_ctx ? *tl_ctx : g_primary; }
 
 // Tuning knobs are process-wide (documented so in bpgpu.h): results never depend on them.
+constexpr size_t DEFAULT_FREEZE_LEN = 1u << 14, DEFAULT_IPA_TABLE_MIN = 1u << 12;
 std::atomic<int> g_window_bits{0};
-std::atomic<size_t> g_freeze_len{1u << 14};  // vectors this short defer the generator fold (0 = never)
+std::atomic<size_t> g_freeze_len{DEFAULT_FREEZE_LEN};  // vectors this short defer the generator fold (0 = never)
 std::atomic<bool> g_pair_fold{true};         // long rounds fold their generators two rounds at a time (k_fold_joint4)
-std::atomic<size_t> g_ipa_table_min{1u << 12};  // frozen generators at least this many get a fixed-base table (0 = never)
+std::atomic<size_t> g_ipa_table_min{DEFAULT_IPA_TABLE_MIN};  // frozen generators at least this many get a fixed-base table (0 = never)
 
 // Serialises the calls on the current context; with an explicit context (an IPA session's) that context is
 // also made current for the scope.
@@ -290,12 +341,13 @@ hipError_t upload_async(void* dst, const void* src, size_t bytes, hipStream_t st
   if ((e = hipEventRecord(U.fence, st)) != hipSuccess) return e;
   const size_t nch = (bytes + Uploader::CH - 1) / Uploader::CH;
   const int device = cx().device;
+  const int nt = U.nt;
   hipError_t err[Uploader::T];
   U.pool.run([&](int w) {
     hipError_t r = hipSetDevice(device);
     if (r == hipSuccess) r = hipStreamWaitEvent(U.ws[w], U.fence, 0);
-    for (size_t k = (size_t)w; k < nch && r == hipSuccess; k += Uploader::T) {
-      const int slot = (int)((k / Uploader::T) % Uploader::SLOTS);
+    for (size_t k = (size_t)w; k < nch && r == hipSuccess; k += (size_t)nt) {
+      const int slot = (int)((k / (size_t)nt) % Uploader::SLOTS);
       const size_t off = k * Uploader::CH, len = bytes - off < Uploader::CH ? bytes - off : Uploader::CH;
       if ((r = hipEventSynchronize(U.ev[w][slot])) != hipSuccess) break;  // the slot's previous DMA has drained
       memcpy(U.buf[w][slot], (const char*)src + off, len);
@@ -305,7 +357,7 @@ hipError_t upload_async(void* dst, const void* src, size_t bytes, hipStream_t st
     if (r == hipSuccess) r = hipEventRecord(U.done[w], U.ws[w]);
     err[w] = r;
   });
-  for (int w = 0; w < Uploader::T; w++) {
+  for (int w = 0; w < nt; w++) {
     if (err[w] != hipSuccess) return err[w];
     if ((e = hipStreamWaitEvent(st, U.done[w], 0)) != hipSuccess) return e;
   }
@@ -543,26 +595,36 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
         C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), d_winsum, runs_per_window, slices, fused ? red_tickets : nullptr);
   }
   HIP_TRY(hipEventRecord(C.ev[5], st));
-  // Horner tail on four host threads (three pool workers and this one): a batch of two MSMs gives each MSM
-  // two threads, a single MSM all four.  Thread g of an MSM takes the windows [g W / G, (g+1) W / G) and
+  // Horner tail on up to four host threads (the context's pool workers and this one): a batch of two MSMs gives each
+  // MSM half of them, a single MSM all.  Share g of an MSM takes the windows [g W / G, (g+1) W / G) and
   // runs its doublings down to bit position 0, so the shares simply add up; the critical path is the 255
   // doublings plus 1 / G of the additions.  The workers are woken once the accumulation has finished and spin
-  // (for the few hundred microseconds of the bucket reduction) on a flag: a condition-variable wake-up after the
-  // data has arrived costs about as much as the additions it takes over.
+  // on a flag for about as long as the bucket reduction takes (a condition-variable wake-up after the data has
+  // arrived costs about as much as the additions it takes over); past that they yield between looks, so that on a
+  // host with more contexts than cores a waiting worker never keeps a core from the thread it waits for.
   const uint32_t* hw = (const uint32_t*)C.h_winsum.p;
   const size_t stride = (size_t)Wb * comps * 32;
-  const int G = plan.M > 1 ? 2 : 4;
-  host::HPoint<BF> part[4];
+  const int T = C.hpool.size() + 1;                   // host threads in all
+  const int G = T / plan.M > 1 ? T / plan.M : 1;      // shares per MSM (at most 4)
+  const int ntasks = plan.M * G;
+  host::HPoint<BF> part[8];
   auto task = [&](int t) {
-    const int m = t / G, g = t % G;
-    part[t] = host::HEc<BF>::identity();
-    if (m >= plan.M) return;
-    part[t] = horner<BF>(hw + m * stride, Wb, c, s, nbits, g * Wb / G, (g + 1) * Wb / G);
+    for (int k = t; k < ntasks; k += T) {
+      const int m = k / G, g = k % G;
+      part[k] = horner<BF>(hw + m * stride, Wb, c, s, nbits, g * Wb / G, (g + 1) * Wb / G);
+    }
   };
   HIP_TRY(hipEventSynchronize(C.ev[4]));
   std::atomic<int> go{0};  // 0: wait, 1: the window sums are in host memory, -1: give up
   C.hpool.begin([&](int w) {
-    while (go.load(std::memory_order_acquire) == 0) __builtin_ia32_pause();
+    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
+    uint32_t looks = 0;
+    while (go.load(std::memory_order_acquire) == 0) {
+      if ((++looks & 63u) == 0 && std::chrono::steady_clock::now() > spin_until)
+        std::this_thread::yield();
+      else
+        __builtin_ia32_pause();
+    }
     if (go.load(std::memory_order_acquire) == 1) task(w + 1);
   });
   hipError_t sync_err = hipStreamSynchronize(st);
@@ -1272,23 +1334,47 @@ static __device__ __align__(256) uint32_t scratch[NOALLOC_IP_BLOCKS * 8];
 
 namespace {
 // caller holds C.mu (or is the only one who can see C)
-int ctx_init(Ctx& C, int device) {
+int ctx_init_steps(Ctx& C, int device) {
   int count = 0;
   HIP_TRY(hipGetDeviceCount(&count));
   if (device < 0 || device >= count) return fail(BPGPU_E_ARG, "device %d out of range (%d visible)", device, count);
   HIP_TRY(hipSetDevice(device));
+  C.device = device;
   HIP_TRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
   for (auto& e : C.ev) HIP_TRY(hipEventCreate(&e));
   for (auto& e : C.op_ev) HIP_TRY(hipEventCreate(&e));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   C.num_cus = prop.multiProcessorCount;
-  C.device = device;
   // this device's copy of the allocation-free entry point's scratch array (each GPU has its own address)
   void* sp = nullptr;
   HIP_TRY(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
   C.noalloc_scratch = (uint32_t*)sp;
-  C.hpool.start(3);
+  return 0;
+}
+// the stream and the events of a context (also of one whose initialisation stopped half-way)
+void ctx_destroy_handles(Ctx& C) {
+  for (auto& e : C.ev) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  for (auto& e : C.op_ev) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  if (C.stream) (void)hipStreamDestroy(C.stream);
+  C.stream = nullptr;
+  C.noalloc_scratch = nullptr;
+}
+int ctx_init(Ctx& C, int device) {
+  const int rc = ctx_init_steps(C, device);
+  if (rc != 0) {
+    const std::string why = g_err;
+    ctx_destroy_handles(C);
+    g_err = why;
+    return rc;
+  }
+  C.hpool.start(helper_threads());
   C.ready = true;
   return 0;
 }
@@ -1309,10 +1395,8 @@ void ctx_release(Ctx& C) {
   C.h_winsum.release();
   C.up.release();
   C.hpool.stop();
-  for (auto& e : C.ev) (void)hipEventDestroy(e);
-  for (auto& e : C.op_ev) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(C.stream);
-  C.noalloc_scratch = nullptr;
+  ctx_destroy_handles(C);
+  C.msm_timed = false;
   C.ready = false;
 }
 }  // namespace
@@ -1331,6 +1415,7 @@ int bpgpu_init(int device) {
 // Open IPA sessions keep device memory of their context: shutting down under them would leave them with
 // dangling pointers, so the call is refused (returns without releasing anything) until they are freed.
 void bpgpu_shutdown(void) {
+  std::lock_guard<std::mutex> run(g_shard_run_mu);
   std::lock_guard<std::mutex> reg(g_reg_mu);
   {
     std::lock_guard<std::mutex> lk(g_primary.mu);
@@ -1345,6 +1430,7 @@ void bpgpu_shutdown(void) {
     ctx_release(*c);
   }
   g_shards.clear();
+  g_ctx_count.store(1);
   std::lock_guard<std::mutex> lk(g_primary.mu);
   ctx_release(g_primary);
 }
@@ -1367,7 +1453,23 @@ int bpgpu_set_pair_fold(int enable) {
 }
 
 int bpgpu_set_ipa_table(size_t min_len) {
-  g_ipa_table_min.store(min_len == 1 ? (size_t)1 << 12 : min_len);
+  g_ipa_table_min.store(min_len == 1 ? DEFAULT_IPA_TABLE_MIN : min_len);
+  return 0;
+}
+
+void bpgpu_reset_tuning(void) {
+  g_window_bits.store(0);
+  g_freeze_len.store(DEFAULT_FREEZE_LEN);
+  g_pair_fold.store(true);
+  g_ipa_table_min.store(DEFAULT_IPA_TABLE_MIN);
+}
+
+int bpgpu_get_tuning(size_t out[4]) {
+  if (!out) return fail(BPGPU_E_ARG, "null pointer");
+  out[0] = (size_t)g_window_bits.load();
+  out[1] = g_freeze_len.load();
+  out[2] = g_pair_fold.load() ? 1 : 0;
+  out[3] = g_ipa_table_min.load();
   return 0;
 }
 
@@ -2496,6 +2598,7 @@ struct bpgpu_sharded_gens {
 };
 
 int bpgpu_sharded_init(int n_ctx, const int* devices) {
+  std::lock_guard<std::mutex> run(g_shard_run_mu);
   std::lock_guard<std::mutex> reg(g_reg_mu);
   if (n_ctx < 1 || n_ctx > 64) return fail(BPGPU_E_ARG, "n_ctx = %d outside [1, 64]", n_ctx);
   if (!g_shards.empty()) {
@@ -2505,11 +2608,15 @@ int bpgpu_sharded_init(int n_ctx, const int* devices) {
     return fail(BPGPU_E_STATE, "the sharded contexts are already initialised with another device list");
   }
   std::vector<std::unique_ptr<Ctx>> made;
+  g_ctx_count.store(n_ctx);  // sizes every context's helper threads (helper_threads())
   for (int g = 0; g < n_ctx; g++) {
     made.emplace_back(new Ctx());
     int rc = ctx_init(*made.back(), devices ? devices[g] : g);
     if (rc) {
-      for (auto& c : made) ctx_release(*c);
+      const std::string why = g_err;
+      for (auto& c : made) ctx_release(*c);  // the one that failed has already dropped its handles
+      g_ctx_count.store(1);
+      g_err = why;
       return rc;
     }
   }
@@ -2525,7 +2632,7 @@ int bpgpu_sharded_count(void) {
 
 static int msm_sharded_host(int curve, const uint64_t* points, int fmt, const uint64_t* scalars, size_t n,
                             uint64_t out_xy_inf[9]) {
-  std::lock_guard<std::mutex> reg(g_reg_mu);
+  std::lock_guard<std::mutex> run(g_shard_run_mu);
   if (g_shards.empty()) return fail(BPGPU_E_NOINIT, "bpgpu_sharded_init has not been called");
   TRY(check_curve(curve));
   if (!out_xy_inf) return fail(BPGPU_E_ARG, "null output");
@@ -2560,7 +2667,7 @@ int bpgpu_msm_sharded_affine(int curve, const uint64_t* points_xy, const uint64_
 }
 
 int bpgpu_sharded_gens_load(int curve, const uint64_t* points, size_t n, int fmt, bpgpu_sharded_gens** out) {
-  std::lock_guard<std::mutex> reg(g_reg_mu);
+  std::lock_guard<std::mutex> run(g_shard_run_mu);
   if (g_shards.empty()) return fail(BPGPU_E_NOINIT, "bpgpu_sharded_init has not been called");
   TRY(check_curve(curve));
   if (!out || (n && !points)) return fail(BPGPU_E_ARG, "null pointer");
@@ -2601,7 +2708,7 @@ int bpgpu_sharded_gens_load(int curve, const uint64_t* points, size_t n, int fmt
 }
 
 int bpgpu_sharded_gens_msm(bpgpu_sharded_gens* h, const uint64_t* scalars, uint64_t out_xy_inf[9]) {
-  std::lock_guard<std::mutex> reg(g_reg_mu);
+  std::lock_guard<std::mutex> run(g_shard_run_mu);
   if (!h || !out_xy_inf || (h->n && !scalars)) return fail(BPGPU_E_ARG, "null pointer");
   if (g_shards.size() != h->d_pts.size()) return fail(BPGPU_E_STATE, "the sharded contexts changed since the generators were loaded");
   std::vector<std::array<uint64_t, 9>> parts(g_shards.size());
@@ -2620,7 +2727,7 @@ int bpgpu_sharded_gens_msm(bpgpu_sharded_gens* h, const uint64_t* scalars, uint6
 
 void bpgpu_sharded_gens_free(bpgpu_sharded_gens* h) {
   if (!h) return;
-  std::lock_guard<std::mutex> reg(g_reg_mu);
+  std::lock_guard<std::mutex> run(g_shard_run_mu);
   if (g_shards.size() == h->d_pts.size())
     (void)run_on_shards([&](int g) {
       (void)hipStreamSynchronize(cx().stream);

@@ -828,7 +828,8 @@ __global__ void __launch_bounds__(256) k_ip_partial(const uint32_t* __restrict__
   const uint32_t* b = sb + 8ull * pr.b_off;
   uint32_t tid = threadIdx.x;
   Fe acc = F::zero();
-  for (uint32_t i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+  // 64-bit index: n may be anything up to 2^32 - 1 and i + gridDim.x * 256 must not wrap
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + tid; i < n; i += (uint64_t)gridDim.x * 256) {
     const uint4* pa = reinterpret_cast<const uint4*>(a + 8ull * i);
     const uint4* pb = reinterpret_cast<const uint4*>(b + 8ull * i);
     uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];

@@ -26,6 +26,8 @@ SIGNATURES = {
     "bpgpu_set_freeze_len": (c_int, [c_size_t]),
     "bpgpu_set_pair_fold": (c_int, [c_int]),
     "bpgpu_set_ipa_table": (c_int, [c_size_t]),
+    "bpgpu_reset_tuning": (None, []),
+    "bpgpu_get_tuning": (c_int, [POINTER(c_size_t)]),
     "bpgpu_msm": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_msm_affine": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_ip": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -141,6 +143,18 @@ def set_ipa_table(min_len: int):
 
 def set_freeze_len(n: int):
     _check(load().bpgpu_set_freeze_len(n))
+
+
+def reset_tuning():
+    """All four process-wide knobs back to the shipped defaults."""
+    load().bpgpu_reset_tuning()
+
+
+def get_tuning():
+    """{window_bits, freeze_len, pair_fold, ipa_table_min} as the library holds them now."""
+    out = (c_size_t * 4)()
+    _check(load().bpgpu_get_tuning(out))
+    return {"window_bits": int(out[0]), "freeze_len": int(out[1]), "pair_fold": bool(out[2]), "ipa_table_min": int(out[3])}
 
 
 def msm(curve, points_xyz, scalars):

@@ -71,6 +71,11 @@ int bpgpu_set_pair_fold(int enable);
  * 1 = the default (2^12: twelve rounds left at least), otherwise the threshold itself.  Tuning only: results are
  * identical either way. */
 int bpgpu_set_ipa_table(size_t min_len);
+/* Back to the shipped defaults of all four knobs (automatic window, freeze length 2^14, pair folding on, table
+ * from 2^12 frozen generators), and the current values: out[0] window bits (0 = automatic), out[1] freeze
+ * length, out[2] pair folding (0/1), out[3] table threshold.  No reference counterpart (tuning only). */
+void bpgpu_reset_tuning(void);
+int bpgpu_get_tuning(size_t out[4]);
 
 /* ---- variable-base MSM ------------------------------------------------------
  * Replaces `pippenger_msm` (= `crate::util::msm`), reference src/util/msm.rs:88-193
@@ -121,14 +126,15 @@ int bpgpu_points_from_device(int curve, const void* d_points, size_t n, uint64_t
 int bpgpu_msm_device(int curve, const void* d_points, const void* d_scalars, size_t n,
                      uint64_t out_xy_inf[9]);
 int bpgpu_ip_device(int curve, const void* d_a, const void* d_b, size_t n, uint64_t out[4]);
-/* bpgpu_ip_device for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs; the
+/* bpgpu_ip_device for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, code that must not disturb the allocator).  NO COUNTERPART IN THE REFERENCE.  Same inputs; the
  * result (one ark-form scalar, 32 B) is written to caller-owned DEVICE memory d_out; the block partial sums
  * live in a fixed 32 KiB file-scope device array instead of a grow-only workspace, and the call performs no
- * hipMalloc / hipFree / allocating library routine.  n <= BPGPU_IP_NOALLOC_MAX_N, larger n is BPGPU_E_ARG.
- * Every call on a GPU shares that GPU's array: calls through one context are serialised by the library, but
- * calls that overlap on one GPU from two contexts (bpgpu_sharded_init with a repeated device) or two
- * processes' worth of streams race on it.  Returns after the stream has drained. */
+ * hipMalloc / hipFree / allocating library routine.  It launches on the library's own stream and returns after
+ * that stream has drained (so it is not itself capturable into a HIP graph).  n <= BPGPU_IP_NOALLOC_MAX_N,
+ * larger n is BPGPU_E_ARG.  The array is per process and per GPU: calls through one context are serialised by
+ * the library, but two contexts of one process on the same GPU (bpgpu_sharded_init with a repeated device, or a
+ * shard context beside the primary one) share it, and such calls must not overlap. */
 #define BPGPU_IP_NOALLOC_MAX_N ((size_t)0xffffffffu)
 int bpgpu_ip_device_noalloc(int curve, const void* d_a, const void* d_b, size_t n, void* d_out);
 int bpgpu_fold_scalars_device(int curve, const void* d_v, size_t n_out, const uint64_t s_lo[4],

@@ -96,3 +96,33 @@ def test_static_archive_defines_every_declared_symbol():
     defined = set(re.findall(r"\bT (bpgpu_[a-z0-9_]+)", out))
     missing = [s for s in header_symbols() if s not in defined]
     assert not missing, f"not defined in libbpgpu.a: {missing}"
+
+
+def test_tuning_knobs_have_getters_and_a_reset():
+    """The four process-wide knobs can be read back and restored to the shipped defaults: tests that
+    change a schedule restore the REAL defaults, whatever they are."""
+    defaults = {"window_bits": 0, "freeze_len": 1 << 14, "pair_fold": True, "ipa_table_min": 1 << 12}
+    ffi.reset_tuning()
+    assert ffi.get_tuning() == defaults
+    ffi.set_window_bits(13)
+    ffi.set_freeze_len(1 << 9)
+    ffi.set_pair_fold(False)
+    ffi.set_ipa_table(0)
+    assert ffi.get_tuning() == {"window_bits": 13, "freeze_len": 1 << 9, "pair_fold": False, "ipa_table_min": 0}
+    ffi.set_ipa_table(1)  # 1 = the default threshold
+    assert ffi.get_tuning()["ipa_table_min"] == 1 << 12
+    with pytest.raises(ffi.BpGpuError):
+        ffi.set_window_bits(21)
+    ffi.reset_tuning()
+    assert ffi.get_tuning() == defaults
+
+
+def test_ip_index_is_64_bit():
+    """bpgpu_ip_device[_noalloc] admit n up to 2^32 - 1; the kernel's loop index must not wrap below that
+    (a 32-bit `i += gridDim.x * 256` would for n > 2^32 - 262144)."""
+    src = open(os.path.join(ROOT, "bulletproofs_amd", "csrc", "kernels.cuh")).read()
+    body = src[src.index("k_ip_partial("):src.index("k_ip_final(")]
+    assert "for (uint64_t i" in body and "for (uint32_t i" not in body
+    lib = ffi.load()
+    assert lib.bpgpu_ip_device(0, None, None, 1 << 32, None) == -1
+    assert lib.bpgpu_ip_device_noalloc(0, None, None, 1 << 32, None) == -1

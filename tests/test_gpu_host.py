@@ -203,8 +203,7 @@ def test_ipa_prove_verify_full_size_2_20(bp, c):
             for key in ("ls", "rs", "challenges", "final_a", "final_b"):
                 assert (alt[key] == pf[key]).all(), (pair, freeze, key)
     finally:
-        ffi.set_freeze_len(1 << 15)
-        ffi.set_pair_fold(True)
+        ffi.reset_tuning()
     gens = bp.DeviceGens(cid, A, B, q)
     try:
         got = bp.bp_prove_cached(gens, a, b, seed)

@@ -288,9 +288,7 @@ def test_bp_prove_deferred_fold_equivalence(ffi, freeze, pair, table):
         sess.free()
         assert (ga == fa).all() and (gb == fb).all()
     finally:
-        ffi.set_freeze_len(1 << 15)
-        ffi.set_pair_fold(True)
-        ffi.set_ipa_table(1)
+        ffi.reset_tuning()
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
@@ -323,9 +321,7 @@ def test_pair_folding_whole_proofs(ffi, c, n, freeze):
             sess.free()
             assert (ga == fa).all() and (gb == fb).all(), pair
     finally:
-        ffi.set_freeze_len(1 << 15)
-        ffi.set_pair_fold(True)
-        ffi.set_ipa_table(1)
+        ffi.reset_tuning()
 
 
 @pytest.mark.parametrize("pair", [False, True], ids=["roundfold", "pairfold"])
@@ -376,8 +372,7 @@ def test_session_monic_fold_edge_cases(ffi, c, pair):
                 assert H.scalars_from_abi(c, ga) == a and H.scalars_from_abi(c, gb) == b
         sess.free()
     finally:
-        ffi.set_freeze_len(1 << 15)
-        ffi.set_pair_fold(True)
+        ffi.reset_tuning()
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
