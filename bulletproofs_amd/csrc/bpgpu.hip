@@ -204,7 +204,7 @@ int helper_threads() {
 // pinned memory 57 GB/s (tools/h2d_probe.py), and one host core copies 32 GB/s: three persistent worker
 // threads stage 4 MiB chunks into pinned buffers, each chunk's DMA following on the worker's own stream.
 struct Uploader {
-  static constexpr int T = 3, SLOTS = 2;  // T: the most staging threads; nt of them run (helper_threads())
+  static constexpr int T = 8, SLOTS = 2;  // T: the most staging threads; nt of them run (staging_threads())
   static constexpr size_t CH = 4u << 20, MIN_BYTES = 8u << 20;
   bool ready = false;
   int nt = T;
@@ -212,14 +212,20 @@ struct Uploader {
   hipStream_t ws[T] = {};
   hipEvent_t ev[T][SLOTS] = {};
   hipEvent_t fence = nullptr, done[T] = {};
+  hipEvent_t pdone[2][T] = {};  // point uploads (PtUpload): worker w has enqueued every chunk of phase p
   Pool pool;
   hipError_t init() {
     if (ready) return hipSuccess;
     nt = helper_threads();
+    if (const char* ev_nt = getenv("BPGPU_STAGING_THREADS")) {  // tuning / experiments
+      const int v = atoi(ev_nt);
+      if (v >= 1 && v <= T) nt = v;
+    }
     hipError_t e = hipEventCreateWithFlags(&fence, hipEventDisableTiming);
     for (int w = 0; w < nt && e == hipSuccess; w++) {
       e = hipStreamCreateWithFlags(&ws[w], hipStreamNonBlocking);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&done[w], hipEventDisableTiming);
+      for (int ph = 0; ph < 2 && e == hipSuccess; ph++) e = hipEventCreateWithFlags(&pdone[ph][w], hipEventDisableTiming);
       for (int k = 0; k < SLOTS && e == hipSuccess; k++) {
         e = hipHostMalloc(&buf[w][k], CH, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[w][k], hipEventDisableTiming);
@@ -241,6 +247,10 @@ struct Uploader {
         ev[w][k] = nullptr;
       }
       if (done[w]) (void)hipEventDestroy(done[w]);
+      for (int ph = 0; ph < 2; ph++) {
+        if (pdone[ph][w]) (void)hipEventDestroy(pdone[ph][w]);
+        pdone[ph][w] = nullptr;
+      }
       if (ws[w]) (void)hipStreamDestroy(ws[w]);
       done[w] = nullptr;
       ws[w] = nullptr;
@@ -277,6 +287,19 @@ struct Ctx {
   Pool hpool;  // up to three host threads (helper_threads()) that share the Horner tail with the caller's thread
   PinnedBuf h_winsum;  // window sums land here (pinned: the copy is a plain DMA)
   Uploader up;
+  // chunked point upload in flight (pt_upload_begin .. pt_upload_end)
+  struct PtChunk {
+    const uint64_t* src;
+    uint32_t count;
+    int fmt;
+    uint32_t* d_dst;
+    uint8_t* d_stage;
+    int phase;
+  };
+  std::vector<PtChunk> pt_chunks;
+  std::atomic<int> pt_phase_count[2];
+  hipError_t pt_err[Uploader::T] = {};
+  bool pt_active = false;
   // the buffers of the last closed IPA session, kept for the next one (a prover makes proof after proof of
   // one size; hipMalloc + hipFree of 460 MB cost about a millisecond per proof)
   DevBuf ipa_pts, ipa_sc;
@@ -689,6 +712,156 @@ int points_out(int curve, const uint32_t* d_in, uint32_t* d_out, size_t n) {
   return 0;
 }
 
+// ---- pipelined point upload ------------------------------------------------------------------------------
+// Host points (ark Jacobian 96 B or ark affine 64 B) -> dev affine in HBM, in chunks of PT_CHUNK points that the context's
+// staging threads push one after the other: copy into a pinned slot, DMA on the thread's own stream, conversion kernel
+// (k_points_in) on that same stream -- so conversion of chunk k overlaps the DMA of chunk k+1 and nothing of it sits
+// on the context's main stream.  A Jacobian chunk whose Z coordinates are all 1 (every point of both reference recipes:
+// G::rand normalises, examples/msm_bench.rs:41, src/relations/ipa.rs:28-36) is compacted to x | y while it is staged: a
+// third fewer bytes cross PCIe.  The check reads what the staging copy reads anyway; a chunk with any other Z (or an
+// identity, Z = 0) goes up as it is.
+// Segments carry a phase (0 or 1): the caller can start device work that needs only the phase-0 points while the
+// phase-1 points are still crossing PCIe (the prover's first round: L needs A_hi | B_lo, R the other halves).
+//   pt_upload_begin  starts the staging threads and returns; the caller's arrays are read until pt_upload_end returns
+//   pt_upload_wait   blocks until every chunk of `phase` has been enqueued, then orders stream `st` after them
+//   pt_upload_end    joins the staging threads (every chunk enqueued; all phases) and reports their first error
+struct PtSeg {
+  const uint64_t* src;
+  size_t n;
+  int fmt;  // 0 jacobian, 1 affine
+  uint32_t* d_dst;
+  int phase;
+};
+constexpr uint32_t PT_CHUNK = 32768;  // 3 MiB of Jacobian points: fits a 4 MiB pinned slot
+
+// stages `count` points into buf; returns the bytes to send and the format they are in
+template <int BF>
+size_t stage_points(const uint64_t* src, uint32_t count, int fmt, void* buf, int* out_fmt) {
+  if (fmt == 1) {
+    memcpy(buf, src, (size_t)count * 64);
+    *out_fmt = 1;
+    return (size_t)count * 64;
+  }
+  const uint64_t o0 = FieldConsts<BF>::H_ONE[0], o1 = FieldConsts<BF>::H_ONE[1], o2 = FieldConsts<BF>::H_ONE[2],
+                 o3 = FieldConsts<BF>::H_ONE[3];
+  uint64_t* d = (uint64_t*)buf;
+  uint64_t bad = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    const uint64_t* q = src + 12ull * i;
+    memcpy(d + 8ull * i, q, 64);
+    bad |= (q[8] ^ o0) | (q[9] ^ o1) | (q[10] ^ o2) | (q[11] ^ o3);
+  }
+  if (bad == 0) {
+    *out_fmt = 1;
+    return (size_t)count * 64;
+  }
+  memcpy(buf, src, (size_t)count * 96);
+  *out_fmt = 0;
+  return (size_t)count * 96;
+}
+
+int pt_upload_begin(int curve, const PtSeg* segs, int nseg, hipStream_t st) {
+  Ctx& C = cx();
+  Uploader& U = C.up;
+  if (C.pt_active) return fail(BPGPU_E_STATE, "a point upload is already in flight on this context");
+  HIP_TRY(U.init());
+  size_t total = 0;
+  for (int g = 0; g < nseg; g++) total += segs[g].n;
+  TRY(C.st_pts_in.ensure((total ? total : 1) * 96));
+  C.pt_chunks.clear();
+  uint8_t* stage = (uint8_t*)C.st_pts_in.p;
+  for (int ph = 0; ph < 2; ph++)
+    for (int g = 0; g < nseg; g++) {
+      if (segs[g].phase != ph) continue;
+      for (size_t o = 0; o < segs[g].n; o += PT_CHUNK) {
+        const uint32_t cnt = (uint32_t)(segs[g].n - o < PT_CHUNK ? segs[g].n - o : PT_CHUNK);
+        C.pt_chunks.push_back(Ctx::PtChunk{segs[g].src + o * (segs[g].fmt == 0 ? 12 : 8), cnt, segs[g].fmt, segs[g].d_dst + 16ull * o,
+                                            stage, ph});
+        stage += (size_t)cnt * 96;
+      }
+    }
+  HIP_TRY(hipEventRecord(U.fence, st));  // the staging area and the destination are free once st gets here
+  C.pt_phase_count[0].store(0);
+  C.pt_phase_count[1].store(0);
+  const int device = C.device, nt = U.nt;
+  Ctx* ctx = &C;
+  C.pt_active = true;
+  U.pool.begin([ctx, device, nt, curve](int w) {
+    Ctx& C = *ctx;
+    Uploader& U = C.up;
+    hipError_t r = hipSetDevice(device);
+    if (r == hipSuccess) r = hipStreamWaitEvent(U.ws[w], U.fence, 0);
+    int cur = 0;
+    auto close_phases = [&](int upto) {  // every phase below `upto` is complete for this worker (also after an error)
+      while (cur < upto) {
+        if (r == hipSuccess) r = hipEventRecord(U.pdone[cur][w], U.ws[w]);
+        C.pt_phase_count[cur].fetch_add(1, std::memory_order_release);
+        cur++;
+      }
+    };
+    const size_t nch = C.pt_chunks.size();
+    size_t mine = 0;
+    for (size_t k = (size_t)w; k < nch; k += (size_t)nt, mine++) {
+      const Ctx::PtChunk& ch = C.pt_chunks[k];
+      close_phases(ch.phase);
+      if (r != hipSuccess) continue;
+      const int slot = (int)(mine % Uploader::SLOTS);
+      if ((r = hipEventSynchronize(U.ev[w][slot])) != hipSuccess) continue;  // the slot's previous DMA has drained
+      int cfmt = 0;
+      const size_t bytes = curve == BPGPU_PALLAS ? stage_points<0>(ch.src, ch.count, ch.fmt, U.buf[w][slot], &cfmt)
+                                                 : stage_points<1>(ch.src, ch.count, ch.fmt, U.buf[w][slot], &cfmt);
+      if ((r = hipMemcpyAsync(ch.d_stage, U.buf[w][slot], bytes, hipMemcpyHostToDevice, U.ws[w])) != hipSuccess) continue;
+      if ((r = hipEventRecord(U.ev[w][slot], U.ws[w])) != hipSuccess) continue;
+      if (curve == BPGPU_PALLAS)
+        k_points_in<0><<<cdiv(ch.count, 64), 64, 0, U.ws[w]>>>((const uint32_t*)ch.d_stage, ch.d_dst, ch.count, cfmt);
+      else
+        k_points_in<1><<<cdiv(ch.count, 64), 64, 0, U.ws[w]>>>((const uint32_t*)ch.d_stage, ch.d_dst, ch.count, cfmt);
+      r = hipGetLastError();
+    }
+    close_phases(2);
+    C.pt_err[w] = r;
+  });
+  return 0;
+}
+
+int pt_upload_wait(int phase, hipStream_t st) {
+  Ctx& C = cx();
+  Uploader& U = C.up;
+  if (!C.pt_active) return fail(BPGPU_E_STATE, "no point upload in flight");
+  uint32_t looks = 0;
+  while (C.pt_phase_count[phase].load(std::memory_order_acquire) < U.nt) {
+    if ((++looks & 255u) == 0) std::this_thread::yield(); else __builtin_ia32_pause();
+  }
+  for (int w = 0; w < U.nt; w++) HIP_TRY(hipStreamWaitEvent(st, U.pdone[phase][w], 0));
+  return 0;
+}
+
+int pt_upload_end() {
+  Ctx& C = cx();
+  if (!C.pt_active) return 0;
+  C.up.pool.wait();
+  C.pt_active = false;
+  for (int w = 0; w < C.up.nt; w++)
+    if (C.pt_err[w] != hipSuccess) return fail(BPGPU_E_HIP, "point upload failed: %s", hipGetErrorString(C.pt_err[w]));
+  return 0;
+}
+
+// the whole thing for one array on the context's stream: d_out is valid for work enqueued on st after the call
+int upload_points(int curve, const uint64_t* points, size_t n, int fmt, uint32_t* d_out, hipStream_t st) {
+  if (n == 0) return 0;
+  if (n * (fmt == 0 ? 96 : 64) < Uploader::MIN_BYTES) {
+    Ctx& C = cx();
+    TRY(C.st_pts_in.ensure(n * 96));
+    HIP_TRY(hipMemcpyAsync(C.st_pts_in.p, points, n * (fmt == 0 ? 96 : 64), hipMemcpyHostToDevice, st));
+    return points_in(curve, C.st_pts_in.as<uint32_t>(), d_out, n, fmt);
+  }
+  PtSeg seg{points, n, fmt, d_out, 0};
+  TRY(pt_upload_begin(curve, &seg, 1, st));
+  int rc = pt_upload_wait(0, st);
+  int rc2 = pt_upload_end();
+  return rc ? rc : rc2;
+}
+
 // <a, b> for up to two pairs at once (a's offsets are relative to d_a, b's to d_b); results (ark form) land in
 // d_out0 / d_out1.  d_partial: room for 2 * ip_blocks(n) block sums of 32 bytes.
 uint32_t ip_blocks(uint32_t n) {
@@ -1068,6 +1241,9 @@ struct bpgpu_ipa {
   uint32_t* d_sc;
   bool pooled;  // d_pts / d_sc belong to the context's pool
   bool lr_done;
+  // L, R of the first round, computed by bpgpu_ipa_begin while the generators were still crossing PCIe
+  bool lr_cached;
+  uint64_t l_cache[9], r_cache[9];
   // deferred generator folding (kernels.cuh, k_frozen_*)
   size_t freeze_cap;     // room reserved: n0 <= freeze_cap
   size_t freeze_thresh;  // vectors this short freeze for good
@@ -1512,10 +1688,7 @@ int bpgpu_points_to_device(int curve, const uint64_t* points, size_t n, int fmt,
   if (fmt != 0 && fmt != 1) return fail(BPGPU_E_ARG, "fmt must be 0 (jacobian) or 1 (affine)");
   if (n == 0) return 0;
   if (!points || !d_out) return fail(BPGPU_E_ARG, "null pointer");
-  size_t bytes = n * (fmt == 0 ? 96 : 64);
-  TRY(cx().st_pts_in.ensure(bytes));
-  HIP_TRY(upload_async(cx().st_pts_in.p, points, bytes, cx().stream));
-  TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), (uint32_t*)d_out, n, fmt));
+  TRY(upload_points(curve, points, n, fmt, (uint32_t*)d_out, cx().stream));
   HIP_TRY(hipStreamSynchronize(cx().stream));
   return 0;
 }
@@ -1552,22 +1725,28 @@ static int msm_host(int curve, const uint64_t* points, int fmt, const uint64_t* 
   TRY(check_curve(curve));
   if (!out_xy_inf) return fail(BPGPU_E_ARG, "null output");
   if (n && (!points || !scalars)) return fail(BPGPU_E_ARG, "null pointer");
+  // Scalars first, then the points in chunks on the staging threads' streams (pt_upload_begin): the sort needs the
+  // scalars only and is enqueued while the -- two to three times larger -- point array is still crossing PCIe; the
+  // accumulation is ordered after the last chunk's conversion (points_ready -> pt_upload_wait).
+  const bool piped = n * (size_t)(fmt == 0 ? 96 : 64) >= Uploader::MIN_BYTES;
   if (n) {
-    size_t pbytes = n * (fmt == 0 ? 96 : 64);
-    TRY(cx().st_pts_in.ensure(pbytes));
     TRY(cx().st_pts.ensure(n * 64));
     TRY(cx().st_sc.ensure(n * 32));
     HIP_TRY(upload_async(cx().st_sc.p, scalars, n * 32, cx().stream));
+    if (piped) {
+      PtSeg seg{points, n, fmt, cx().st_pts.as<uint32_t>(), 0};
+      TRY(pt_upload_begin(curve, &seg, 1, cx().stream));
+    }
   }
-  // scalars first: the sort runs on them while the (three times larger) points are uploaded and converted
   const std::function<int()> points_ready = [&]() -> int {
     if (!n) return 0;
-    const size_t pbytes = n * (fmt == 0 ? 96 : 64);
-    HIP_TRY(upload_async(cx().st_pts_in.p, points, pbytes, cx().stream));
-    return points_in(curve, cx().st_pts_in.as<uint32_t>(), cx().st_pts.as<uint32_t>(), n, fmt);
+    if (piped) return pt_upload_wait(0, cx().stream);
+    return upload_points(curve, points, n, fmt, cx().st_pts.as<uint32_t>(), cx().stream);
   };
-  return msm_dispatch(curve, cx().st_pts.as<uint32_t>(), cx().st_sc.as<uint32_t>(), single_plan((uint32_t)n),
-                      (uint64_t(*)[9])out_xy_inf, &points_ready);
+  const int rc = msm_dispatch(curve, cx().st_pts.as<uint32_t>(), cx().st_sc.as<uint32_t>(), single_plan((uint32_t)n),
+                              (uint64_t(*)[9])out_xy_inf, &points_ready);
+  const int rc_up = pt_upload_end();  // the caller's arrays are read until here, whatever happened above
+  return rc ? rc : rc_up;
 }
 
 int bpgpu_msm(int curve, const uint64_t* points_xyz, const uint64_t* scalars, size_t n, uint64_t out_xy_inf[9]) {
@@ -1759,10 +1938,21 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
     HIP_TRY(hipMemcpyAsync(dp + 16ull * 2 * np, d_q, 64, hipMemcpyDeviceToDevice, st));
   } else {
     if (n) {
-      HIP_TRY(upload_async(stg, a_gens_xyz, n * 96, st));
-      HIP_TRY(upload_async(stg + n * 96, b_gens_xyz, n * 96, st));
-      TRY(points_in(curve, (uint32_t*)stg, dp, n, 0));
-      TRY(points_in(curve, (uint32_t*)(stg + n * 96), dp + 16ull * np, n, 0));
+      PtSeg segs[2] = {{a_gens_xyz, n, 0, dp, 0}, {b_gens_xyz, n, 0, dp + 16ull * np, 0}};
+      if (n * 96 >= Uploader::MIN_BYTES) {
+        // the staging area is st_pts_in: the proof's few points below go behind the generators' 2 n slots
+        TRY(C.st_pts_in.ensure((2 * n + 1 + 2 * k) * 96));
+        stg = (uint8_t*)C.st_pts_in.p;
+        TRY(pt_upload_begin(curve, segs, 2, st));
+        const int rc_w = pt_upload_wait(0, st), rc_e = pt_upload_end();
+        TRY(rc_w);
+        TRY(rc_e);
+      } else {
+        HIP_TRY(upload_async(stg, a_gens_xyz, n * 96, st));
+        HIP_TRY(upload_async(stg + n * 96, b_gens_xyz, n * 96, st));
+        TRY(points_in(curve, (uint32_t*)stg, dp, n, 0));
+        TRY(points_in(curve, (uint32_t*)(stg + n * 96), dp + 16ull * np, n, 0));
+      }
     }
     HIP_TRY(upload_async(stg + 2 * n * 96, ip_gen_xyz, 96, st));
     TRY(points_in(curve, (uint32_t*)(stg + 2 * n * 96), dp + 16ull * 2 * np, 1, 0));
@@ -2203,6 +2393,7 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
   s->np = np;
   s->len = np;
   s->lr_done = false;
+  s->lr_cached = false;
   s->d_pts = nullptr;
   s->d_sc = nullptr;
   const size_t freeze_len = g_freeze_len.load();
@@ -2270,18 +2461,48 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
         rc = fail(BPGPU_E_HIP, "device copy failed");
         break;
       }
-    } else {
-      if ((rc = cx().st_pts_in.ensure((2 * n + 1) * 96)) != 0) break;
-      uint8_t* stg = (uint8_t*)cx().st_pts_in.p;
-      if ((n && (upload_async(stg, a_gens_xyz, n * 96, st) != hipSuccess ||
-                 upload_async(stg + n * 96, b_gens_xyz, n * 96, st) != hipSuccess)) ||
-          upload_async(stg + 2 * n * 96, ip_gen_xyz, 96, st) != hipSuccess) {
-        rc = fail(BPGPU_E_HIP, "upload failed");
-        break;
+    } else if (n * 96 >= Uploader::MIN_BYTES && np >= 4 && np / 2 > s->freeze_thresh) {
+      // Large vectors from the host: the generators go up in two phases -- what L of the first round reads
+      // (A[np/2..], B[..np/2], Q: bp_iter.rs:68-74), then what R reads (:75-81) -- and the first round's two MSMs run
+      // here, one after the other, each as soon as its half has arrived: L's sort overlaps the first half's DMA, L's
+      // accumulation the second half's.  round_lr then hands the cached pair out.  (n > np / 2 by the choice of np.)
+      const size_t h = np / 2;
+      uint32_t* dA = s->d_pts;
+      uint32_t* dB = s->d_pts + 16 * np;
+      PtSeg segs[5] = {{a_gens_xyz + 12 * h, n - h, 0, dA + 16 * h, 0},
+                       {b_gens_xyz, h, 0, dB, 0},
+                       {ip_gen_xyz, 1, 0, s->d_pts + 32 * np, 0},
+                       {a_gens_xyz, h, 0, dA, 1},
+                       {b_gens_xyz + 12 * h, n - h, 0, dB + 16 * h, 1}};
+      if ((rc = pt_upload_begin(curve, segs, 5, st)) != 0) break;
+      const uint32_t hn = (uint32_t)h, npu = (uint32_t)np;
+      IpPair pl{0u, npu + hn}, pr{hn, npu};
+      rc = ip_launch(curve, s->d_sc, s->d_sc, pl, pr, 2, hn, s->d_sc + 8ull * (2 * np), s->d_sc + 8ull * (2 * np + 1));
+      for (int side = 0; side < 2 && rc == 0; side++) {
+        MsmPlan plan;
+        memset(&plan, 0, sizeof plan);
+        plan.M = 1;
+        plan.n = 2 * hn + 1;
+        if (side == 0) {
+          plan.seg[0][0] = MsmSeg{hn, 0u, hn};
+          plan.seg[0][1] = MsmSeg{npu, npu + hn, hn};
+          plan.seg[0][2] = MsmSeg{2 * npu, 2 * npu, 1};
+        } else {
+          plan.seg[0][0] = MsmSeg{0u, hn, hn};
+          plan.seg[0][1] = MsmSeg{npu + hn, npu, hn};
+          plan.seg[0][2] = MsmSeg{2 * npu, 2 * npu + 1, 1};
+        }
+        const std::function<int()> ready = [&]() -> int { return pt_upload_wait(side, st); };
+        rc = msm_dispatch(curve, s->d_pts, s->d_sc, plan, (uint64_t(*)[9])(side == 0 ? s->l_cache : s->r_cache), &ready);
       }
-      if ((rc = points_in(curve, (uint32_t*)stg, s->d_pts, n, 0)) != 0) break;
-      if ((rc = points_in(curve, (uint32_t*)(stg + n * 96), s->d_pts + 16 * np, n, 0)) != 0) break;
-      if ((rc = points_in(curve, (uint32_t*)(stg + 2 * n * 96), s->d_pts + 32 * np, 1, 0)) != 0) break;
+      const int rc_up = pt_upload_end();  // the caller's arrays are read until here
+      if (rc == 0) rc = rc_up;
+      if (rc != 0) break;
+      s->lr_cached = true;
+    } else {
+      if ((rc = upload_points(curve, a_gens_xyz, n, 0, s->d_pts, st)) != 0) break;
+      if ((rc = upload_points(curve, b_gens_xyz, n, 0, s->d_pts + 16 * np, st)) != 0) break;
+      if ((rc = upload_points(curve, ip_gen_xyz, 1, 0, s->d_pts + 32 * np, st)) != 0) break;
     }
     if (np <= s->freeze_thresh && !s->freeze_disabled && np > 1 && ((rc = ipa_freeze(s)) != 0 || (rc = ipa_build_table(s)) != 0)) break;
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(BPGPU_E_HIP, "sync failed");
@@ -2354,6 +2575,13 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
   if (s->len <= 1) return fail(BPGPU_E_STATE, "the vectors already have length 1");
   if (s->lr_done) return fail(BPGPU_E_STATE, "round_fold must follow round_lr");
   const uint32_t n = (uint32_t)(s->len / 2), np = (uint32_t)s->np;
+  if (s->lr_cached) {  // the first round of a large session: computed by bpgpu_ipa_begin
+    memcpy(l_xy_inf, s->l_cache, 72);
+    memcpy(r_xy_inf, s->r_cache, 72);
+    s->lr_cached = false;
+    s->lr_done = true;
+    return 0;
+  }
   // c_L = <a[..n], b[n..]>, c_R = <a[n..], b[..n]>   (bp_iter.rs:73,80)
   IpPair pl{0u, np + n}, pr{n, np};
   TRY(ip_launch(s->curve, s->d_sc, s->d_sc, pl, pr, 2, n, s->d_sc + 8ull * (2 * np), s->d_sc + 8ull * (2 * np + 1)));
@@ -2645,12 +2873,10 @@ static int msm_sharded_host(int curve, const uint64_t* points, int fmt, const ui
     const size_t lo = (size_t)g * n / P, hi = (size_t)(g + 1) * n / P, cnt = hi - lo;
     Ctx& C = cx();
     if (cnt) {
-      TRY(C.st_pts_in.ensure(cnt * pw * 8));
       TRY(C.st_pts.ensure(cnt * 64));
       TRY(C.st_sc.ensure(cnt * 32));
-      HIP_TRY(upload_async(C.st_pts_in.p, points + lo * pw, cnt * pw * 8, C.stream));
       HIP_TRY(upload_async(C.st_sc.p, scalars + lo * 4, cnt * 32, C.stream));
-      TRY(points_in(curve, C.st_pts_in.as<uint32_t>(), C.st_pts.as<uint32_t>(), cnt, fmt));
+      TRY(upload_points(curve, points + lo * pw, cnt, fmt, C.st_pts.as<uint32_t>(), C.stream));
     }
     return msm_dispatch(curve, C.st_pts.as<uint32_t>(), C.st_sc.as<uint32_t>(), single_plan((uint32_t)cnt),
                         (uint64_t(*)[9])parts[g].data());
@@ -2688,9 +2914,7 @@ int bpgpu_sharded_gens_load(int curve, const uint64_t* points, size_t n, int fmt
     Ctx& C = cx();
     HIP_TRY(hipMalloc(&h->d_pts[g], (cnt ? cnt : 1) * 64));
     if (cnt) {
-      TRY(C.st_pts_in.ensure(cnt * pw * 8));
-      HIP_TRY(upload_async(C.st_pts_in.p, points + lo * pw, cnt * pw * 8, C.stream));
-      TRY(points_in(curve, C.st_pts_in.as<uint32_t>(), (uint32_t*)h->d_pts[g], cnt, fmt));
+      TRY(upload_points(curve, points + lo * pw, cnt, fmt, (uint32_t*)h->d_pts[g], C.stream));
       HIP_TRY(hipStreamSynchronize(C.stream));
     }
     return 0;
