@@ -271,7 +271,8 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
-  hipEvent_t op_ev[2] = {};  // around the last ip / fold launch (bpgpu_last_op_ms)
+  hipEvent_t op_ev[2] = {};  // around the last ip / fold / vector-utility operation (bpgpu_last_op_ms)
+  int op_depth = 0;          // OpSpan nesting: only the outermost span records the events
   int num_cus = 256;
   float msm_ms[8] = {};
   bool msm_timed = false;  // ev[0..5] bracket the phases of a completed MSM
@@ -339,6 +340,18 @@ struct CtxLock {
   ~CtxLock() {
     lk.unlock();
     tl_ctx = prev;
+  }
+};
+
+// Brackets the kernels of one operation with the context's op events (bpgpu_last_op_ms).  Spans nest: an operation made
+// of several launches (the k-ary generator fold: k - 1 monic folds) is timed as a whole by its outermost span.
+struct OpSpan {
+  Ctx& C;
+  explicit OpSpan(Ctx& c) : C(c) {
+    if (C.op_depth++ == 0) (void)hipEventRecord(C.op_ev[0], C.stream);
+  }
+  ~OpSpan() {
+    if (--C.op_depth == 0) (void)hipEventRecord(C.op_ev[1], C.stream);
   }
 };
 
@@ -873,7 +886,7 @@ int ip_launch_with(int curve, const uint32_t* d_a, const uint32_t* d_b, IpPair p
   Ctx& C = cx();
   const uint32_t nblk = ip_blocks(n);
   dim3 grid(nblk, npairs);
-  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
+  OpSpan span(cx());
   if (curve == BPGPU_PALLAS) {
     k_ip_partial<1><<<grid, 256, 0, C.stream>>>(d_a, d_b, p0, p1, n, d_partial);
     k_ip_final<1><<<npairs, 256, 0, C.stream>>>(d_partial, nblk, d_out0, d_out1);
@@ -881,7 +894,6 @@ int ip_launch_with(int curve, const uint32_t* d_a, const uint32_t* d_b, IpPair p
     k_ip_partial<0><<<grid, 256, 0, C.stream>>>(d_a, d_b, p0, p1, n, d_partial);
     k_ip_final<0><<<npairs, 256, 0, C.stream>>>(d_partial, nblk, d_out0, d_out1);
   }
-  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -905,12 +917,11 @@ int fold_scalars_launch(int curve, uint32_t* v0, uint32_t* o0, const FoldScalars
   const uint32_t cap = (uint32_t)cx().num_cus * 16;
   if (gx > cap) gx = cap;
   dim3 grid(gx, nvec);
-  HIP_TRY(hipEventRecord(cx().op_ev[0], cx().stream));
+  OpSpan span(cx());
   if (curve == BPGPU_PALLAS)
     k_fold_scalars<1><<<grid, 256, 0, cx().stream>>>(v0, o0, s0, v1, o1, s1, n);
   else
     k_fold_scalars<0><<<grid, 256, 0, cx().stream>>>(v0, o0, s0, v1, o1, s1, n);
-  HIP_TRY(hipEventRecord(cx().op_ev[1], cx().stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -960,75 +971,7 @@ int jsf_codes(const uint64_t a[4], const uint64_t b[4], uint32_t* codes, int max
   return pos;
 }
 
-// 256-bit wrapping helpers for the GLV split
-void mul256_wrap(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
-  uint64_t r[4] = {0, 0, 0, 0};
-  for (int i = 0; i < 4; i++) {
-    unsigned __int128 carry = 0;
-    for (int j = 0; i + j < 4; j++) {
-      carry += (unsigned __int128)a[i] * b[j] + r[i + j];
-      r[i + j] = (uint64_t)carry;
-      carry >>= 64;
-    }
-  }
-  memcpy(out, r, 32);
-}
-void sub256_wrap(uint64_t a[4], const uint64_t b[4]) {
-  unsigned __int128 br = 0;
-  for (int i = 0; i < 4; i++) {
-    unsigned __int128 d = (unsigned __int128)a[i] - b[i] - br;
-    a[i] = (uint64_t)d;
-    br = (d >> 64) & 1;
-  }
-}
-void neg256_wrap(uint64_t a[4]) {
-  uint64_t z[4] = {0, 0, 0, 0};
-  sub256_wrap(z, a);
-  memcpy(a, z, 32);
-}
-// (k * g) >> 384 for a 4-limb k and a 5-limb g
-void mul_shift384(const uint64_t k[4], const uint64_t g[5], uint64_t out[4]) {
-  uint64_t r[9] = {0};
-  for (int i = 0; i < 4; i++) {
-    unsigned __int128 carry = 0;
-    for (int j = 0; j < 5; j++) {
-      carry += (unsigned __int128)k[i] * g[j] + r[i + j];
-      r[i + j] = (uint64_t)carry;
-      carry >>= 64;
-    }
-    r[i + 5] = (uint64_t)carry;
-  }
-  out[0] = r[6];
-  out[1] = r[7];
-  out[2] = r[8];
-  out[3] = 0;
-}
-
-// k (canonical, < r) = k1 + k2 lambda (mod r) with short k1, k2; magnitudes and signs out.
-template <int CURVE>
-void glv_split(const uint64_t k[4], uint64_t k1[4], bool& neg1, uint64_t k2[4], bool& neg2) {
-  using CC = CurveConsts<CURVE>;
-  uint64_t c1[4], c2[4], t[4];
-  mul_shift384(k, CC::GLV_G1, c1);
-  mul_shift384(k, CC::GLV_G2, c2);
-  if (CC::GLV_N1_NEG) neg256_wrap(c1);
-  if (CC::GLV_N2_NEG) neg256_wrap(c2);
-  memcpy(k1, k, 32);
-  mul256_wrap(c1, CC::GLV_A1, t);
-  sub256_wrap(k1, t);
-  mul256_wrap(c2, CC::GLV_A2, t);
-  sub256_wrap(k1, t);
-  memset(k2, 0, 32);
-  mul256_wrap(c1, CC::GLV_B1, t);
-  sub256_wrap(k2, t);
-  mul256_wrap(c2, CC::GLV_B2, t);
-  sub256_wrap(k2, t);
-  neg1 = (k1[3] >> 63) != 0;
-  neg2 = (k2[3] >> 63) != 0;
-  if (neg1) neg256_wrap(k1);
-  if (neg2) neg256_wrap(k2);
-}
-
+// (the GLV split k = k1 + k2 lambda and its 256-bit helpers live in kernels.cuh: host and device share them)
 template <int CURVE>
 int make_fold_plan(const uint64_t s_lo_ark[4], const uint64_t s_hi_ark[4], FoldPlan& f) {
   using HFs = host::HF<1 - CURVE>;
@@ -1074,12 +1017,11 @@ int fold_points_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64
     C.fold_ops[2] += (uint64_t)n * (count_codes(f.codes_p, f.len) + count_codes(f.codes_q, f.len));
   }
   dim3 grid(cdiv(n, 64), nvec);
-  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
+  OpSpan span(cx());
   if (curve == BPGPU_PALLAS)
     k_fold_points<0><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, plans, n);
   else
     k_fold_points<1><<<grid, 64, 0, C.stream>>>(g0, o0, g1, o1, plans, n);
-  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1210,12 +1152,11 @@ int fold_monic_pq(int curve, const uint32_t* p0, const uint32_t* q0, uint32_t* o
     C.fold_ops[2] += (uint64_t)n * (count_codes(plans.p[v].codes, plans.p[v].len) + (has_p ? 1u : 0u));
   }
   dim3 grid(cdiv(n, 256), nvec);
-  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
+  OpSpan span(cx());
   if (curve == BPGPU_PALLAS)
     k_fold_monic<0><<<grid, 256, 0, C.stream>>>(p0, q0, o0, p1, q1, o1, plans, n, has_p);
   else
     k_fold_monic<1><<<grid, 256, 0, C.stream>>>(p0, q0, o0, p1, q1, o1, plans, n, has_p);
-  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1368,7 +1309,7 @@ int fold_joint4_launch(int curve, uint32_t* gA, const uint64_t sA[3][4], uint32_
   // short vectors: two lanes an output (half of the chain's additions each) while that still leaves a wave a SIMD
   const bool split = (uint64_t)q * 2 * 2 <= (uint64_t)C.num_cus * 256;
   dim3 grid(split ? cdiv(q, 128) : cdiv(q, 256), 2);
-  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
+  OpSpan span(cx());
   if (split) {
     if (curve == BPGPU_PALLAS)
       k_fold_joint4_split<0><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);
@@ -1378,7 +1319,6 @@ int fold_joint4_launch(int curve, uint32_t* gA, const uint64_t sA[3][4], uint32_
     k_fold_joint4<0><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);
   else
     k_fold_joint4<1><<<grid, 256, 0, C.stream>>>(gA, gA, gB, gB, plans, q);
-  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2041,12 +1981,11 @@ int fold_scalars_kary_launch(int curve, const uint32_t* d_v, size_t ck, size_t k
   uint32_t gx = cdiv(ck, 256);
   const uint32_t cap = (uint32_t)C.num_cus * 16;
   if (gx > cap) gx = cap;
-  HIP_TRY(hipEventRecord(C.op_ev[0], C.stream));
+  OpSpan span(cx());
   if (curve == BPGPU_PALLAS)
     k_fold_scalars_kary<1><<<gx, 256, k * 36, C.stream>>>(d_v, C.st_ip.as<uint32_t>(), d_out, (uint32_t)ck, (uint32_t)k);
   else
     k_fold_scalars_kary<0><<<gx, 256, k * 36, C.stream>>>(d_v, C.st_ip.as<uint32_t>(), d_out, (uint32_t)ck, (uint32_t)k);
-  HIP_TRY(hipEventRecord(C.op_ev[1], C.stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2062,6 +2001,7 @@ int fold_points_kary_launch(int curve, const uint32_t* d_g, size_t ck, size_t k,
     return 0;
   }
   const uint32_t n = (uint32_t)ck;
+  OpSpan span(C);  // the whole fold (k - 1 or k monic folds) is one timed operation
   auto chunk = [&](size_t j) { return d_g + 16ull * j * ck; };
   const bool geo = k >= 2 && (curve == BPGPU_PALLAS ? geometric_from_one<1>(y, k) : geometric_from_one<0>(y, k));
   if (geo) {
@@ -2181,10 +2121,13 @@ int bpgpu_hadamard_points(int curve, const uint64_t* bases_xyz, const uint64_t* 
   HIP_TRY(upload_async(cx().st_sc.p, scalars, n * 32, cx().stream));
   uint32_t* d = cx().st_pts.as<uint32_t>();
   TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), d, n, 0));
-  if (curve == BPGPU_PALLAS)
-    k_hadamard_points<0><<<cdiv(n, 256), 256, 0, cx().stream>>>(d, cx().st_sc.as<uint32_t>(), d, (uint32_t)n);
-  else
-    k_hadamard_points<1><<<cdiv(n, 256), 256, 0, cx().stream>>>(d, cx().st_sc.as<uint32_t>(), d, (uint32_t)n);
+  {
+    OpSpan span(cx());
+    if (curve == BPGPU_PALLAS)
+      k_hadamard_points<0><<<cdiv(n, 256), 256, 0, cx().stream>>>(d, cx().st_sc.as<uint32_t>(), d, (uint32_t)n);
+    else
+      k_hadamard_points<1><<<cdiv(n, 256), 256, 0, cx().stream>>>(d, cx().st_sc.as<uint32_t>(), d, (uint32_t)n);
+  }
   HIP_TRY(hipGetLastError());
   TRY(points_out(curve, d, cx().st_pts_in.as<uint32_t>(), n));
   HIP_TRY(hipMemcpyAsync(out_xyz, cx().st_pts_in.p, n * 96, hipMemcpyDeviceToHost, cx().stream));
@@ -2235,12 +2178,15 @@ static int spmv_run(int curve, const uint32_t* ptr, const uint32_t* idx, const u
   if (vec_len) HIP_TRY(upload_async(B[4].p, vec, vec_len * 32, st));
   const uint32_t grid = cdiv((uint64_t)n_out * SPMV_GROUP, 256);
   const uint32_t* d_perm = perm ? B[2].as<uint32_t>() : nullptr;
-  if (curve == BPGPU_PALLAS)
-    k_spmv<1><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(),
-                                    B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out);
-  else
-    k_spmv<0><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(),
-                                    B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out);
+  {
+    OpSpan span(cx());
+    if (curve == BPGPU_PALLAS)
+      k_spmv<1><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(),
+                                      B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out);
+    else
+      k_spmv<0><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(),
+                                      B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, B[5].p, n_out * 32, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

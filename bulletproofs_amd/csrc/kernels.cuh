@@ -1215,6 +1215,87 @@ __device__ __forceinline__ Aff alpha_point(const Aff& Q, const Fe& inv, const Fe
   return r;
 }
 
+// ---- GLV split, shared by the host (shared fold multipliers, bpgpu.hip) and the device (k_hadamard_points) ----
+// 256-bit wrapping helpers
+BP_HD void mul256_wrap(const uint64_t (&a)[4], const uint64_t (&b)[4], uint64_t (&out)[4]) {
+  uint64_t r[4] = {0, 0, 0, 0};
+  BP_UNROLL
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 carry = 0;
+    BP_UNROLL
+    for (int j = 0; j < 4; j++) {
+      if (i + j < 4) {
+        carry += (unsigned __int128)a[i] * b[j] + r[i + j];
+        r[i + j] = (uint64_t)carry;
+        carry >>= 64;
+      }
+    }
+  }
+  BP_UNROLL
+  for (int i = 0; i < 4; i++) out[i] = r[i];
+}
+BP_HD void sub256_wrap(uint64_t (&a)[4], const uint64_t (&b)[4]) {
+  unsigned __int128 br = 0;
+  BP_UNROLL
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 d = (unsigned __int128)a[i] - b[i] - br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+BP_HD void neg256_wrap(uint64_t (&a)[4]) {
+  uint64_t z[4] = {0, 0, 0, 0};
+  sub256_wrap(z, a);
+  BP_UNROLL
+  for (int i = 0; i < 4; i++) a[i] = z[i];
+}
+// (k * g) >> 384 for a 4-limb k and a 5-limb g
+BP_HD void mul_shift384(const uint64_t (&k)[4], const uint64_t (&g)[5], uint64_t (&out)[4]) {
+  uint64_t r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  BP_UNROLL
+  for (int i = 0; i < 4; i++) {
+    unsigned __int128 carry = 0;
+    BP_UNROLL
+    for (int j = 0; j < 5; j++) {
+      carry += (unsigned __int128)k[i] * g[j] + r[i + j];
+      r[i + j] = (uint64_t)carry;
+      carry >>= 64;
+    }
+    r[i + 5] = (uint64_t)carry;
+  }
+  out[0] = r[6];
+  out[1] = r[7];
+  out[2] = r[8];
+  out[3] = 0;
+}
+// k (canonical, < r) = k1 + k2 lambda (mod r) with short k1, k2 (below 2^129); magnitudes and signs out.
+template <int CURVE>
+BP_HD void glv_split(const uint64_t (&k)[4], uint64_t (&k1)[4], bool& neg1, uint64_t (&k2)[4], bool& neg2) {
+  using CC = CurveConsts<CURVE>;
+  uint64_t c1[4], c2[4], t[4];
+  mul_shift384(k, CC::GLV_G1, c1);
+  mul_shift384(k, CC::GLV_G2, c2);
+  if (CC::GLV_N1_NEG) neg256_wrap(c1);
+  if (CC::GLV_N2_NEG) neg256_wrap(c2);
+  BP_UNROLL
+  for (int i = 0; i < 4; i++) {
+    k1[i] = k[i];
+    k2[i] = 0;
+  }
+  mul256_wrap(c1, CC::GLV_A1, t);
+  sub256_wrap(k1, t);
+  mul256_wrap(c2, CC::GLV_A2, t);
+  sub256_wrap(k1, t);
+  mul256_wrap(c1, CC::GLV_B1, t);
+  sub256_wrap(k2, t);
+  mul256_wrap(c2, CC::GLV_B2, t);
+  sub256_wrap(k2, t);
+  neg1 = (k1[3] >> 63) != 0;
+  neg2 = (k2[3] >> 63) != 0;
+  if (neg1) neg256_wrap(k1);
+  if (neg2) neg256_wrap(k2);
+}
+
 // Vector y (blockIdx.y = 0 / 1):  o[i] = p[i] + s q[i]  (has_p)  or  s q[i]  (!has_p; p is not read).
 // o may alias p or q: a lane reads its own elements before it writes.
 template <int BF>
@@ -1680,43 +1761,127 @@ __global__ void __launch_bounds__(256) k_powers(PowersArgs args, uint32_t* __res
   }
 }
 
-// o[i] = s[i] g[i]  (hadamard_gp, util/mod.rs:70-78: every lane has its own multiplier).  Plain
-// MSB-first double-and-add over the canonical scalar; the mixed add runs under the lanes' bit mask.
-// Back to affine with the workgroup-shared inversion.  o may alias g.
+// o[i] = s[i] g[i]  (hadamard_gp, util/mod.rs:70-78, used at com_r1cs_to_ipa.rs:110: every lane has its own multiplier).
+// Every lane runs the same schedule; only table indices and signs differ:
+//   * GLV on the device: s = k1 + k2 lambda with |k1|, |k2| < 2^129 (glv_split), so the chain is 132 doublings long
+//     instead of 255, with phi(P) = (zeta x, y) as the second base;
+//   * signed 3-bit windows without a carry chain: k' = |k| + sum_j 4 * 8^j, digit_j = (bits 3j..3j+2 of k') - 4 in
+//     [-4, 3]; 44 windows cover k' < 2^132;
+//   * the multiples 2P, 3P, 4P are made once per lane (two doublings, one addition, in Jacobian), brought to affine with
+//     ONE inversion shared by the workgroup, and kept in LDS as unpacked limbs; P itself stays in registers;
+//   * the chain runs in Jacobian coordinates (3 doublings + at most two mixed additions per window); the inversion
+//     back to affine is again the workgroup's.
+// 132 doublings + about 77 additions per output, against 255 + 127 for the plain ladder.  o may alias g.
+constexpr int HAD_WINDOWS = 44;
 template <int BF>
-__global__ void __launch_bounds__(256) k_hadamard_points(const uint32_t* g, const uint32_t* __restrict__ s, uint32_t* o,
-                                                         uint32_t n) {
+__global__ void __launch_bounds__(256, 2) k_hadamard_points(const uint32_t* g, const uint32_t* __restrict__ s, uint32_t* o,
+                                                            uint32_t n) {
   using F = Fp<BF>;
   using FS = Fp<1 - BF>;
   using E = Ec<BF>;
   using IO = PointIo<BF>;
   __shared__ uint32_t tree[512][9];
+  __shared__ int32_t tab[3][18][256];  // 2P, 3P, 4P of this lane: x (9 limbs), y (9 limbs)
+  const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
-  Xyzz acc = E::identity();
+  Aff P;
+  P.inf = true;
+  P.x = F::zero();
+  P.y = F::zero();
+  uint64_t k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
+  bool n1 = false, n2 = false;
   if (active) {
-    const Aff P = IO::load_dev_affine(g + 16ull * i);
+    P = IO::load_dev_affine(g + 16ull * i);
     uint32_t w[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) w[t] = s[8ull * i + t];
     FS::pack(FS::canon(FS::mul(FS::unpack(w), FS::from_const(FS::C::C256TOCANON))), w);
-    if (!P.inf) {
-      for (int b = 254; b >= 0; b--) {
-        acc = E::dbl(acc);
-        if ((w[b >> 5] >> (b & 31)) & 1u) E::madd(acc, P);
+    const uint64_t k[4] = {w[0] | ((uint64_t)w[1] << 32), w[2] | ((uint64_t)w[3] << 32), w[4] | ((uint64_t)w[5] << 32),
+                           w[6] | ((uint64_t)w[7] << 32)};
+    glv_split<BF>(k, k1, n1, k2, n2);
+    // k' = |k| + 0x4924...: every window offset by 4 (0b100 repeated: 0x9249 2492 4924 ... in 64-bit words)
+    const uint64_t off[3] = {0x4924924924924924ull, 0x2492492492492492ull, 0x9ull};  // bits 3j+2 set for j < 44
+    unsigned __int128 c = 0;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      c += (unsigned __int128)k1[t] + off[t];
+      k1[t] = (uint64_t)c;
+      c >>= 64;
+    }
+    c = 0;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      c += (unsigned __int128)k2[t] + off[t];
+      k2[t] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  const bool fin0 = active && !P.inf;
+  // the table: 2P, 3P, 4P in affine through one shared inversion
+  {
+    Jac P2 = E::jidentity(), P3 = E::jidentity(), P4 = E::jidentity();
+    if (fin0) {
+      P2 = E::jdbl(E::jfrom_affine(P));
+      P3 = P2;
+      E::jmadd(P3, P);
+      P4 = E::jdbl(P2);
+    }
+    // on a prime-order curve none of 2P, 3P, 4P is the identity for a finite P
+    const Fe z2 = fin0 ? P2.z : F::one(), z3 = fin0 ? P3.z : F::one(), z4 = fin0 ? P4.z : F::one();
+    const Fe z23 = F::mul(z2, z3);
+    const Fe iv = block_inverse_256<BF>(F::mul(z23, z4), tree);
+    const Fe i4 = F::mul(iv, z23), i23 = F::mul(iv, z4);
+    const Fe i2 = F::mul(i23, z3), i3 = F::mul(i23, z2);
+#pragma unroll 1
+    for (int t = 0; t < 3; t++) {
+      const Jac& J = t == 0 ? P2 : (t == 1 ? P3 : P4);
+      const Fe& zi = t == 0 ? i2 : (t == 1 ? i3 : i4);
+      const Aff A = E::jto_affine_with(J, zi);
+      const Fe ay = F::carry(A.y);
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        tab[t][k][tid] = A.x.l[k];
+        tab[t][9 + k][tid] = ay.l[k];
+      }
+    }
+  }
+  Jac acc = E::jidentity();
+  if (fin0) {
+    const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
+#pragma unroll 1
+    for (int w = HAD_WINDOWS - 1; w >= 0; w--) {
+      acc = E::jdbl(E::jdbl(E::jdbl(acc)));
+      const int pos = 3 * w, wi = pos >> 6, sh = pos & 63;
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {
+        const uint64_t lo = h == 0 ? (wi == 0 ? k1[0] : (wi == 1 ? k1[1] : k1[2])) : (wi == 0 ? k2[0] : (wi == 1 ? k2[1] : k2[2]));
+        const uint64_t hi = h == 0 ? (wi == 0 ? k1[1] : (wi == 1 ? k1[2] : 0ull)) : (wi == 0 ? k2[1] : (wi == 1 ? k2[2] : 0ull));
+        uint32_t bits = (uint32_t)(lo >> sh);
+        if (sh > 61) bits |= (uint32_t)(hi << (64 - sh));
+        const int d = (int)(bits & 7u) - 4;
+        const int mag = d < 0 ? -d : d;
+        Aff t;
+        t.inf = mag == 0;
+        t.x = P.x;
+        t.y = P.y;
+        if (mag >= 2) {
+#pragma unroll
+          for (int k = 0; k < 9; k++) {
+            t.x.l[k] = tab[mag - 2][k][tid];
+            t.y.l[k] = tab[mag - 2][9 + k][tid];
+          }
+        }
+        if (h == 1) t.x = F::mul(t.x, zeta);  // phi(T) = (zeta x, y)
+        const bool neg = (d < 0) != (h == 0 ? n1 : n2);
+        if (neg) t.y = F::neg(t.y);
+        E::jmadd(acc, t);  // skips a zero digit (t.inf)
       }
     }
   }
   const bool fin = active && !acc.inf;
-  const Fe den = fin ? F::mul(acc.zz, acc.zzz) : F::one();
-  const Fe inv = block_inverse_256<BF>(den, tree);
-  if (active) {
-    Aff r;
-    r.inf = !fin;
-    r.x = F::mul(acc.x, F::mul(inv, acc.zzz));
-    r.y = F::mul(acc.y, F::mul(inv, acc.zz));
-    IO::store_dev_affine(o + 16ull * i, r);
-  }
+  const Fe inv = block_inverse_256<BF>(fin ? acc.z : F::one(), tree);
+  if (active) IO::store_dev_affine(o + 16ull * i, E::jto_affine_with(acc, inv));
 }
 
 // Verifier scalars of Bp::verify (bp_iter.rs:25-42,160-164), 2 np of them:

@@ -131,3 +131,11 @@ def test_fold_points_kary_and_hadamard_gp_vs_c_oracle(ffi, c):
     assert (ffi.hadamard_points(cid, g, s) == co.hadamard_points(cid, g, s, threads=8)).all()
     es = H.scalars_abi(c, [0, 1, 2, c.r - 1, (c.r - 1) // 2, 1 << 254 if (1 << 254) < c.r else 5])
     assert (ffi.hadamard_points(cid, pts[:6], es) == co.hadamard_points(cid, pts[:6], es)).all()
+    # the windowed GLV ladder (2P, 3P, 4P table, signed 3-bit digits): small multiples hit the table entries themselves
+    # (accumulator == table point: the doubling branch), the cube roots of unity split into (0, +-1), and -small
+    lam = next(pow(gg, (c.r - 1) // 3, c.r) for gg in range(2, 50) if pow(gg, (c.r - 1) // 3, c.r) != 1)
+    sm = [3, 4, 5, 7, 8, 9, 12, 16, 31, 32, 33, c.r - 2, c.r - 3, c.r - 4, c.r - 5, c.r - 8, lam, lam * lam % c.r, c.r - lam,
+          (lam + 1) % c.r, 2 * lam % c.r, 4 * lam % c.r, (3 * lam + 4) % c.r, (1 << 128) - 1, 1 << 128, (1 << 129) + 5]
+    es = H.scalars_abi(c, sm)
+    gp = np.concatenate([pts[:len(sm) - 1], pts[:1]])  # the last element repeats a base
+    assert (ffi.hadamard_points(cid, gp, es) == co.hadamard_points(cid, gp, es)).all()
