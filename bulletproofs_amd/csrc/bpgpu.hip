@@ -490,6 +490,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     out[m][8] = 1;
   }
   if (plan.n == 0) return 0;
+  if (plan.M < 1 || plan.M > MSM_MAX_BATCH) return fail(BPGPU_E_ARG, "a batch holds 1 to %d MSMs", MSM_MAX_BATCH);
   // fixed-base table mode: the width is the one the table was built for, and all windows of an MSM share a bucket set
   const bool table = plan.table_stride != 0;
   const int c = table ? plan.c : choose_window(plan.n_eff ? plan.n_eff : plan.n, plan.M);
@@ -643,7 +644,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const int T = C.hpool.size() + 1;                   // host threads in all
   const int G = T / plan.M > 1 ? T / plan.M : 1;      // shares per MSM (at most 4)
   const int ntasks = plan.M * G;
-  host::HPoint<BF> part[8];
+  host::HPoint<BF> part[MSM_MAX_BATCH];  // ntasks = M G <= max(M, T)
   auto task = [&](int t) {
     for (int k = t; k < ntasks; k += T) {
       const int m = k / G, g = k % G;
@@ -2080,6 +2081,74 @@ int bpgpu_fold_points_kary(int curve, const uint64_t* g_xyz, size_t ck, size_t k
   TRY(points_out(curve, d_o, cx().st_pts_in.as<uint32_t>(), ck));
   HIP_TRY(hipMemcpyAsync(out_xyz, cx().st_pts_in.p, ck * 96, hipMemcpyDeviceToHost, cx().stream));
   HIP_TRY(hipStreamSynchronize(cx().stream));
+  return 0;
+}
+
+// ---- cross terms of a k-ary round -----------------------------------------------------------------------------
+// X[i, j] = msm(a_gen[j] | b_gen[i] | Q,  a[i] | b[j] | <a[i], b[j]>) over chunks of length ck
+// (src/reductions/ipa_to_bp_unroll.rs:189-194 == src/proofs/bp_rec_kary.rs:52-60), and
+//   pos[t] = sum_{j < k-t-1} X[t+j+1, j],   neg[t] = sum_{j < k-t-1} X[j, t+j+1],   t < k - 1   (:198-215 == :64-76).
+// A sum of MSMs is an MSM over the concatenated operands, and here the concatenations are CONTIGUOUS ranges of the padded
+// vectors: with off = (t+1) ck and m = (k-t-1) ck,
+//   pos[t] = msm(A[..m] | B[off..] | Q,  a[off..] | b[..m] | <a[off..], b[..m]>)
+//   neg[t] = msm(A[off..] | B[..m] | Q,  a[..m] | b[off..] | <a[..m], b[off..]>)
+// -- the three-segment operand form of the prover's L and R.  So the k (k - 1) MSMs of 2 ck + 1 terms (and as many inner
+// products) become 2 (k - 1) MSMs, all of them in ONE batched launch sequence (MsmPlan with M = 2 (k - 1) <= 32; more go in
+// several batches), over operands uploaded once.
+int bpgpu_kary_cross_terms(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz, const uint64_t* ip_gen_xyz,
+                           const uint64_t* a, const uint64_t* b, size_t ck, size_t k, uint64_t* pos_xy_inf,
+                           uint64_t* neg_xy_inf) {
+  CtxLock lk;
+  TRY(check_ready());
+  TRY(check_curve(curve));
+  if (k < 2) return 0;  // no cross terms
+  if (k > 4096 || ck > ((size_t)1 << 26) || ck * k > ((size_t)1 << 26)) return fail(BPGPU_E_ARG, "k-ary round too large");
+  if (!ip_gen_xyz || !pos_xy_inf || !neg_xy_inf) return fail(BPGPU_E_ARG, "null pointer");
+  if (ck && (!a_gens_xyz || !b_gens_xyz || !a || !b)) return fail(BPGPU_E_ARG, "null pointer");
+  Ctx& C = cx();
+  const size_t N = ck * k;
+  const uint32_t Nu = (uint32_t)N;
+  TRY(C.st_pts.ensure((2 * N + 1) * 64));
+  TRY(C.st_sc.ensure((2 * N + 2 * (k - 1)) * 32));
+  uint32_t* dp = C.st_pts.as<uint32_t>();
+  uint32_t* ds = C.st_sc.as<uint32_t>();
+  hipStream_t st = C.stream;
+  if (N) {
+    HIP_TRY(upload_async(ds, a, N * 32, st));
+    HIP_TRY(upload_async(ds + 8 * N, b, N * 32, st));
+    TRY(upload_points(curve, a_gens_xyz, N, 0, dp, st));
+    TRY(upload_points(curve, b_gens_xyz, N, 0, dp + 16 * N, st));
+  }
+  TRY(upload_points(curve, ip_gen_xyz, 1, 0, dp + 32 * N, st));
+  // the 2 (k - 1) summed inner products, two per launch
+  for (size_t t = 0; t + 1 < k; t++) {
+    const uint32_t off = (uint32_t)((t + 1) * ck), m = Nu - off;
+    IpPair pp{off, Nu}, pn{0u, Nu + off};
+    TRY(ip_launch(curve, ds, ds, pp, pn, 2, m, ds + 8ull * (2 * N + 2 * t), ds + 8ull * (2 * N + 2 * t + 1)));
+  }
+  static thread_local uint64_t out[MSM_MAX_BATCH][9];
+  for (size_t t0 = 0; t0 + 1 < k; t0 += MSM_MAX_BATCH / 2) {
+    const size_t cnt = (k - 1 - t0) < (size_t)(MSM_MAX_BATCH / 2) ? (k - 1 - t0) : (size_t)(MSM_MAX_BATCH / 2);
+    MsmPlan plan;
+    memset(&plan, 0, sizeof plan);
+    plan.M = (int)(2 * cnt);
+    plan.n = 2 * (Nu - (uint32_t)((t0 + 1) * ck)) + 1;  // the longest of the batch
+    for (size_t i = 0; i < cnt; i++) {
+      const size_t t = t0 + i;
+      const uint32_t off = (uint32_t)((t + 1) * ck), m = Nu - off;
+      plan.seg[2 * i][0] = MsmSeg{0u, off, m};
+      plan.seg[2 * i][1] = MsmSeg{Nu + off, Nu, m};
+      plan.seg[2 * i][2] = MsmSeg{2 * Nu, (uint32_t)(2 * N + 2 * t), 1};
+      plan.seg[2 * i + 1][0] = MsmSeg{off, 0u, m};
+      plan.seg[2 * i + 1][1] = MsmSeg{Nu, Nu + off, m};
+      plan.seg[2 * i + 1][2] = MsmSeg{2 * Nu, (uint32_t)(2 * N + 2 * t + 1), 1};
+    }
+    TRY(msm_dispatch(curve, dp, ds, plan, out));
+    for (size_t i = 0; i < cnt; i++) {
+      memcpy(pos_xy_inf + 9 * (t0 + i), out[2 * i], 72);
+      memcpy(neg_xy_inf + 9 * (t0 + i), out[2 * i + 1], 72);
+    }
+  }
   return 0;
 }
 

@@ -24,18 +24,20 @@ namespace bpgpu {
 struct MsmSeg {
   uint32_t pt_off, sc_off, count;
 };
+constexpr int MSM_MAX_BATCH = 32;
 struct MsmPlan {
-  int M;       // number of independent MSMs in this batch (1 or 2)
+  int M;       // number of independent MSMs in this batch (the prover's L, R pair: 2; a k-ary round's cross terms: up to MSM_MAX_BATCH)
   int W;       // windows per MSM
   int c;       // window width in bits; digits are signed, |d| <= 2^(c-1)
-  uint32_t n;  // slots per MSM (sum of its segment counts)
+  uint32_t n;  // slots per MSM: the sum of its segment counts, or the largest such sum when the MSMs of a batch differ
+               // in length (the slots of a shorter one past its own end are padding: zero digits, no entries)
   uint32_t n_eff;  // slots whose scalar can be non-zero, if the caller knows (0 = n): sizes the windows
   // Fixed-base table mode (0 = off): the point array holds, for every point index p < table_stride, its multiples
   // 2^(c w) P at index w * table_stride + p (w < W).  Window w of a slot then takes the w-th multiple, every
   // window's digits fall into ONE bucket set per MSM (W times fewer buckets to reduce) and the window sum needs
   // no doublings.  c is then given by the caller (the width the table was built for).
   uint32_t table_stride;
-  MsmSeg seg[2][3];
+  MsmSeg seg[MSM_MAX_BATCH][3];
 };
 
 __device__ __forceinline__ uint32_t extract_bits(const uint32_t (&w)[8], int pos, int c) {
@@ -102,10 +104,11 @@ __device__ __forceinline__ uint32_t wg_excl_scan_1024(uint32_t v, uint32_t* wsum
   return base + inc - v;
 }
 
-// slot -> (point index, scalar index); returns false past the end
-__device__ __forceinline__ bool slot_lookup(const MsmPlan& plan, uint64_t gid, int& m, uint32_t& pt_idx,
-                                            uint32_t& sc_idx) {
-  if (gid >= (uint64_t)plan.M * plan.n) return false;
+// slot -> (point index, scalar index); returns 0 past the end of the batch, 1 for a pair, 2 for a padding slot (past the
+// end of an MSM shorter than plan.n)
+__device__ __forceinline__ int slot_lookup(const MsmPlan& plan, uint64_t gid, int& m, uint32_t& pt_idx,
+                                           uint32_t& sc_idx) {
+  if (gid >= (uint64_t)plan.M * plan.n) return 0;
   m = (int)(gid / plan.n);
   uint32_t t = (uint32_t)(gid % plan.n);
   int s = 0;
@@ -113,9 +116,10 @@ __device__ __forceinline__ bool slot_lookup(const MsmPlan& plan, uint64_t gid, i
     t -= plan.seg[m][s].count;
     s++;
   }
+  if (t >= plan.seg[m][s].count) return 2;
   pt_idx = plan.seg[m][s].pt_off + t;
   sc_idx = plan.seg[m][s].sc_off + t;
-  return true;
+  return 1;
 }
 
 // digit word of a (slot, window): |digit| | sign << 31; 0 = zero digit, no entry
@@ -135,8 +139,14 @@ __global__ void __launch_bounds__(1024) k_part_count(MsmPlan plan, SortPlan sp, 
     uint64_t gid = (uint64_t)tile * 1024 + threadIdx.x;
     int m;
     uint32_t pt_idx, sc_idx;
-    if (!slot_lookup(plan, gid, m, pt_idx, sc_idx)) continue;
+    const int kind = slot_lookup(plan, gid, m, pt_idx, sc_idx);
+    if (kind == 0) continue;
     const uint32_t t = (uint32_t)(gid - (uint64_t)m * plan.n);
+    if (kind == 2) {  // padding: zero digits in every window
+      uint32_t* dz = dig + (uint64_t)m * W * plan.n + t;
+      for (int j = 0; j < W; j++) dz[(uint64_t)j * plan.n] = 0u;
+      continue;
+    }
     const uint4* sp4 = reinterpret_cast<const uint4*>(scalars + 8ull * sc_idx);
     uint4 lo = sp4[0], hi = sp4[1];
     uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};

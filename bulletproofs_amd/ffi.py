@@ -47,6 +47,8 @@ SIGNATURES = {
     "bpgpu_fold_points_kary": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "bpgpu_fold_scalars_kary_device": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "bpgpu_fold_points_kary_device": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "bpgpu_kary_cross_terms": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p,
+                                       c_void_p]),
     "bpgpu_hadamard": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_hadamard_points": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "bpgpu_powers": (c_int, [c_int, c_void_p, c_uint64, c_size_t, c_void_p]),
@@ -226,6 +228,18 @@ def fold_scalars_kary_device(curve, d_v, ck, k, y, d_out):
 
 def fold_points_kary_device(curve, d_g, ck, k, y, d_out):
     _check(load().bpgpu_fold_points_kary_device(curve, d_g.ptr, ck, k, _ptr(_u64(y, 4)), d_out.ptr))
+
+
+def kary_cross_terms(curve, a_gens_xyz, b_gens_xyz, ip_gen_xyz, a, b, k):
+    """(pos, neg): the k - 1 positive and negative cross terms of a k-ary round over already padded vectors
+    (ipa_to_bp_unroll.rs:189-215 == bp_rec_kary.rs:52-76), as xy_inf rows."""
+    A, B, q = _u64(a_gens_xyz, 12), _u64(b_gens_xyz, 12), _u64(ip_gen_xyz, 12)
+    a, b = _u64(a, 4), _u64(b, 4)
+    assert len(A) == len(B) == len(a) == len(b) and k >= 1 and len(a) % k == 0
+    ck = len(a) // k
+    pos, neg = np.zeros((max(k - 1, 0), 9), np.uint64), np.zeros((max(k - 1, 0), 9), np.uint64)
+    _check(load().bpgpu_kary_cross_terms(curve, _ptr(A), _ptr(B), _ptr(q), _ptr(a), _ptr(b), ck, k, _ptr(pos), _ptr(neg)))
+    return pos, neg
 
 
 def hadamard(curve, a, b):

@@ -437,6 +437,21 @@ std::vector<G> fold_chunks(const std::vector<G>& v, size_t k, const std::vector<
                                out.empty() ? nullptr : out.data()->v));
   return out;
 }
+// Cross terms of a k-ary round (bp_rec_kary.rs:52-76 == ipa_to_bp_unroll.rs:189-215) over padded vectors of k chunks
+template <int CURVE>
+void kary_cross_terms(const std::vector<G>& a_gen, const std::vector<G>& b_gen, const G& q, const std::vector<Fr>& a,
+                      const std::vector<Fr>& b, size_t ck, size_t k, std::vector<G>& pos, std::vector<G>& neg) {
+  const size_t m = k > 0 ? k - 1 : 0;
+  std::vector<uint64_t> po(9 * (m ? m : 1)), ne(9 * (m ? m : 1));
+  check(bpgpu_kary_cross_terms(CURVE, a_gen.empty() ? nullptr : a_gen.data()->v, b_gen.empty() ? nullptr : b_gen.data()->v, q.v,
+                               a.empty() ? nullptr : a.data()->v, b.empty() ? nullptr : b.data()->v, ck, k, po.data(), ne.data()));
+  pos.clear();
+  neg.clear();
+  for (size_t t = 0; t < m; t++) {
+    pos.push_back(PointOps<CURVE>::from_xy_inf(&po[9 * t]));
+    neg.push_back(PointOps<CURVE>::from_xy_inf(&ne[9 * t]));
+  }
+}
 // scale_vec (util/mod.rs:25-38) and sum_vecs (:40-55) on their own: the fold with one chunk, and the
 // fold with every multiplier one
 template <int CURVE, class Z>
@@ -1012,27 +1027,10 @@ struct KaryBp {
     if (b.size() != a.size() || a_gen.size() != a.size() || b_gen.size() != a.size()) throw Panic("assertion failed: vector sizes");
     const size_t ck = a.size() / k;
     const G& q = instance.gens.ip_gen;
-    // X[i, j] = a[i] * A[j] + b[j] * B[i] + <a[i], b[j]> * Q   (:52-60)
-    auto x = [&](size_t i, size_t j) {
-      std::vector<G> pts(a_gen.begin() + j * ck, a_gen.begin() + (j + 1) * ck);
-      pts.insert(pts.end(), b_gen.begin() + i * ck, b_gen.begin() + (i + 1) * ck);
-      pts.push_back(q);
-      std::vector<Fr> sc(a.begin() + i * ck, a.begin() + (i + 1) * ck);
-      sc.insert(sc.end(), b.begin() + j * ck, b.begin() + (j + 1) * ck);
-      sc.push_back(util::ip<CURVE>(a.data() + i * ck, ck, b.data() + j * ck, ck));
-      return util::msm<CURVE>(pts, sc);
-    };
+    // X[i, j] = a[i] * A[j] + b[j] * B[i] + <a[i], b[j]> * Q   (:52-60) and the sums over it (:64-76): one call, which
+    // merges the k (k - 1) MSMs into 2 (k - 1) over contiguous ranges and runs them as one batch
     StepOut out;
-    for (size_t i = 0; i + 1 < k; i++) {  // :64-70
-      std::vector<G> xs;
-      for (size_t j = 0; j < k - i - 1; j++) xs.push_back(x(i + j + 1, j));
-      out.pos_cross.push_back(util::sum_points<CURVE>(xs));
-    }
-    for (size_t i = 0; i + 1 < k; i++) {  // :74-76
-      std::vector<G> xs;
-      for (size_t j = 0; j < k - i - 1; j++) xs.push_back(x(j, i + j + 1));
-      out.neg_cross.push_back(util::sum_points<CURVE>(xs));
-    }
+    util::kary_cross_terms<CURVE>(a_gen, b_gen, q, a, b, ck, k, out.pos_cross, out.neg_cross);
     absorb_vec(fs, out.pos_cross);
     absorb_vec(fs, out.neg_cross);
     const Fr xc = fs.rand_scalar<CURVE>(), x_inv = S::inverse(xc);

@@ -160,6 +160,17 @@ int bpgpu_fold_scalars_kary_device(int curve, const void* d_v, size_t ck, size_t
                                    void* d_out);
 int bpgpu_fold_points_kary_device(int curve, const void* d_g, size_t ck, size_t k, const uint64_t* y,
                                   void* d_out);
+/* Cross terms of one k-ary round.  Replaces the closure `x(i, j)` and the two sums over it at reference
+ * src/reductions/ipa_to_bp_unroll.rs:189-215 == src/proofs/bp_rec_kary.rs:52-76:
+ *   X[i, j] = msm(a_gen[j] | b_gen[i] | Q,  a[i] | b[j] | ip(a[i], b[j]))    (chunks of length ck of the padded vectors)
+ *   pos[t]  = sum_{j < k-t-1} X[t+j+1, j],    neg[t] = sum_{j < k-t-1} X[j, t+j+1],    t < k - 1.
+ * a_gens_xyz, b_gens_xyz: k * ck jacobian points, a, b: k * ck scalars (the caller has padded them:
+ * zero_pad_to_multiple / zero_intersperse_to_multiple); pos_xy_inf, neg_xy_inf receive k - 1 results (72 B each).
+ * The k (k - 1) MSMs are merged into 2 (k - 1) over contiguous operand ranges and run as one batch; the group elements
+ * are the reference's.  k < 2: nothing is written. */
+int bpgpu_kary_cross_terms(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_gens_xyz,
+                           const uint64_t* ip_gen_xyz, const uint64_t* a, const uint64_t* b, size_t ck, size_t k,
+                           uint64_t* pos_xy_inf, uint64_t* neg_xy_inf);
 /* out[i] = a[i] * b[i].  Replaces `hadamard`, reference src/util/mod.rs:80-85 (caller asserts
  * equal length). */
 int bpgpu_hadamard(int curve, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);

@@ -67,6 +67,7 @@ extern "C" {
     pub fn bpgpu_fold_points_kary(curve: i32, g_xyz: *const u64, ck: usize, k: usize, y: *const u64, out_xyz: *mut u64) -> i32;
     pub fn bpgpu_fold_scalars_kary_device(curve: i32, d_v: *const c_void, ck: usize, k: usize, y: *const u64, d_out: *mut c_void) -> i32;
     pub fn bpgpu_fold_points_kary_device(curve: i32, d_g: *const c_void, ck: usize, k: usize, y: *const u64, d_out: *mut c_void) -> i32;
+    pub fn bpgpu_kary_cross_terms(curve: i32, a_gens_xyz: *const u64, b_gens_xyz: *const u64, ip_gen_xyz: *const u64, a: *const u64, b: *const u64, ck: usize, k: usize, pos_xy_inf: *mut u64, neg_xy_inf: *mut u64) -> i32;
     pub fn bpgpu_hadamard(curve: i32, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> i32;
     pub fn bpgpu_hadamard_points(curve: i32, bases_xyz: *const u64, scalars: *const u64, n: usize, out_xyz: *mut u64) -> i32;
     pub fn bpgpu_powers(curve: i32, f: *const u64, start: u64, n: usize, out: *mut u64) -> i32;

@@ -139,3 +139,50 @@ def test_fold_points_kary_and_hadamard_gp_vs_c_oracle(ffi, c):
     es = H.scalars_abi(c, sm)
     gp = np.concatenate([pts[:len(sm) - 1], pts[:1]])  # the last element repeats a base
     assert (ffi.hadamard_points(cid, gp, es) == co.hadamard_points(cid, gp, es)).all()
+
+
+def _cross_terms_by_the_reference_recipe(c, cid, A, B, q, a, b, k):
+    """pos / neg exactly as ipa_to_bp_unroll.rs:189-215 writes them: k (k - 1) separate MSMs X[i, j] (Oracle B), summed
+    (big-integer model's affine addition)."""
+    ck = len(a) // k
+
+    def ch(v, i):
+        return v[i * ck:(i + 1) * ck]
+
+    def x(i, j):
+        pts = np.concatenate([ch(A, j), ch(B, i), q.reshape(1, 12)])
+        sc = np.concatenate([ch(a, i), ch(b, j), co.ip(cid, ch(a, i), ch(b, j)).reshape(1, 4)])
+        r = co.msm_pippenger(cid, pts, sc, threads=8)
+        return H.jac_from_abi(c, r.reshape(1, 12))[0]
+
+    def total(ps):
+        acc = None
+        for p in ps:
+            acc = pm.aff_add(c, acc, p)
+        return acc
+    pos = [total([x(i + j + 1, j) for j in range(k - i - 1)]) for i in range(k - 1)]
+    neg = [total([x(j, i + j + 1) for j in range(k - i - 1)]) for i in range(k - 1)]
+    return pos, neg
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,k", [(1024, 8), (60, 3), (38, 19), (4, 2), (7, 7)])
+def test_kary_cross_terms_batched(ffi, c, n, k):
+    """bpgpu_kary_cross_terms (one batch of 2 (k - 1) merged MSMs; two batches at k = 19) against the reference's recipe of
+    k (k - 1) separate MSMs: identical group elements, with zero padding (identity points, zero scalars) and a
+    duplicated generator among the operands."""
+    cid = c.curve_id
+    A, B, q, a, b, _ = co.ipa_inputs(cid, n)
+    ident = co.normalise(cid, np.zeros((1, 12), np.uint64))
+    if n >= 38:
+        A, a = A.copy(), a.copy()
+        A[n - 1], a[n - 1] = ident[0], 0        # zero_pad_to_multiple leaves identities / zeros at the end
+        A[3] = A[2]
+        a[5] = 0
+    pos, neg = ffi.kary_cross_terms(cid, A, B, q, a, b, k)
+    want_pos, want_neg = _cross_terms_by_the_reference_recipe(c, cid, A, B, q, a, b, k)
+    assert [H.xy_inf_to_affine(c, p) for p in pos] == want_pos
+    assert [H.xy_inf_to_affine(c, p) for p in neg] == want_neg
+    # k = 1: no cross terms, nothing written
+    p1, n1 = ffi.kary_cross_terms(cid, A, B, q, a, b, 1)
+    assert p1.shape == (0, 9) and n1.shape == (0, 9)
