@@ -614,13 +614,19 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
                                              chunk_counter, glog);
   k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
   HIP_TRY(hipEventRecord(C.ev[4], st));
-  k_reduce1<BF><<<cdiv(nruns, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
+  // few runs (fewer quads than the chip has lanes at two waves a SIMD): the chain of 2 S additions per run is what the
+  // stage takes, so a quad shares each addition (kernels.cuh, quad_add); many runs: one lane each, bound by throughput
+  if ((uint64_t)nruns * 4 <= (uint64_t)C.num_cus * 4 * 64 * 2 + 8192 && !getenv("BPGPU_NO_QUAD"))
+    k_reduce1_quad<BF><<<cdiv((uint64_t)nruns * 4, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
+  else
+    k_reduce1<BF><<<cdiv(nruns, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
   {
     // slices per component: about 1024 waves in all (one per SIMD), at least one value per lane.  Every
     // slice pays a 6-step wave tree on top of its lanes' sums, so more, shorter slices cost more additions
     const uint32_t outputs = (uint32_t)(comps * plan.M * Wb), half = runs_per_window >> 1;
     uint32_t slices = 1;
-    while (slices < 64 && 2 * slices * outputs <= 1024 && 2 * slices * 64 <= half) slices *= 2;
+    static const uint32_t r2_waves = getenv("BPGPU_R2_WAVES") ? (uint32_t)atoi(getenv("BPGPU_R2_WAVES")) : 1024u;
+    while (slices < 64 && 2 * slices * outputs <= r2_waves && 2 * slices * 64 <= half) slices *= 2;
     const uint32_t groups = cdiv(slices, 4);  // a workgroup adds up its four slices itself
     // More than one workgroup per output (the prover's short rounds): the last one to finish adds up all of them --
     // its addition code is warm, where a third kernel for two additions spent 39 us on a launch and cold fetches.
@@ -2245,16 +2251,24 @@ static int spmv_run(int curve, const uint32_t* ptr, const uint32_t* idx, const u
     HIP_TRY(upload_async(B[3].p, vals, nnz * 32, st));
   }
   if (vec_len) HIP_TRY(upload_async(B[4].p, vec, vec_len * 32, st));
-  const uint32_t grid = cdiv((uint64_t)n_out * SPMV_GROUP, 256);
+  // lanes per row: two when the rows are short throughout, eight otherwise
+  uint32_t max_len = 0;
+  for (size_t r = 0; r < n_out; r++) max_len = ptr[r + 1] - ptr[r] > max_len ? ptr[r + 1] - ptr[r] : max_len;
+  const bool narrow = max_len <= 64 && nnz <= 6 * n_out;
+  const uint32_t group = narrow ? 2u : 8u;
+  const uint32_t grid = cdiv((uint64_t)n_out * group, 256);
   const uint32_t* d_perm = perm ? B[2].as<uint32_t>() : nullptr;
   {
     OpSpan span(cx());
-    if (curve == BPGPU_PALLAS)
-      k_spmv<1><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(),
-                                      B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out);
-    else
-      k_spmv<0><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(),
-                                      B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out);
+#define BP_SPMV(SF, G)                                                                                          \
+  k_spmv<SF, G><<<grid, 256, 0, st>>>(B[0].as<uint32_t>(), B[1].as<uint32_t>(), d_perm, B[3].as<uint32_t>(), \
+                                      B[4].as<uint32_t>(), B[5].as<uint32_t>(), (uint32_t)n_out)
+    if (curve == BPGPU_PALLAS) {
+      if (narrow) BP_SPMV(1, 2u); else BP_SPMV(1, 8u);
+    } else {
+      if (narrow) BP_SPMV(0, 2u); else BP_SPMV(0, 8u);
+    }
+#undef BP_SPMV
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, B[5].p, n_out * 32, hipMemcpyDeviceToHost, st));

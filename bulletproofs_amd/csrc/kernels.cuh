@@ -495,6 +495,95 @@ __device__ __forceinline__ Xyzz group_sum_xyzz(Xyzz acc, int first) {
   return acc;
 }
 
+// ---- quad-cooperative addition -----------------------------------------------------------------------------------
+// The bucket reduction of a small MSM (the prover's short rounds, 2^16 points and below) is a CHAIN of some twenty
+// dependent XYZZ additions on a handful of lanes: a lone wave issues an instruction every five clocks, so one addition
+// (fourteen multiplications one after the other) is eight microseconds however idle the chip is.  Here the four lanes of
+// a quad hold the SAME two operands and share the multiplications of ONE addition: four rounds of one multiplication
+// per lane (add-2008-s has depth four), results passed round the quad by DPP moves (one VALU slot per limb, no LDS).
+//   round 1:  U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1          P = U2 - U1, R = S2 - S1
+//   round 2:  PP = P P    | RR = R R    | ZZ1 ZZ2      | ZZZ1 ZZZ2
+//   round 3:  PPP = P PP  | Q = U1 PP   | ZZ3 = (ZZ1 ZZ2) PP | (idle)           X3 = RR - PPP - 2 Q
+//   round 4:  R (Q - X3)  | S1 PPP      | (idle)       | ZZZ3 = (ZZZ1 ZZZ2) PPP  Y3 = difference of the first two
+// About a third of the instructions of Ec::add on the critical path.  Every lane of the quad returns the same sum.
+// All four lanes of a quad must call together with identical operands (quads are aligned groups of four lanes).
+template <int J>
+__device__ __forceinline__ Fe fe_quad_bcast(const Fe& a) {
+  Fe r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.l[k] = __builtin_amdgcn_update_dpp(a.l[k], a.l[k], J * 0x55, 0xf, 0xf, false);  // quad_perm:[J,J,J,J]
+  return r;
+}
+__device__ __forceinline__ Fe fe_sel4(uint32_t q, const Fe& a0, const Fe& a1, const Fe& a2, const Fe& a3) {
+  Fe r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int32_t lo = (q & 1u) ? a1.l[k] : a0.l[k], hi = (q & 1u) ? a3.l[k] : a2.l[k];
+    r.l[k] = (q & 2u) ? hi : lo;
+  }
+  return r;
+}
+template <int BF>
+__device__ __forceinline__ Xyzz quad_add(const Xyzz& a, const Xyzz& b) {
+  using F = Fp<BF>;
+  using E = Ec<BF>;
+  if (a.inf) return b;  // the operands are identical across the quad, so whole quads take these branches together
+  if (b.inf) return a;
+  const uint32_t q = threadIdx.x & 3u;
+  const Fe r1 = F::mul(fe_sel4(q, a.x, b.x, a.y, b.y), fe_sel4(q, b.zz, a.zz, b.zzz, a.zzz));
+  const Fe U1 = fe_quad_bcast<0>(r1), U2 = fe_quad_bcast<1>(r1), S1 = fe_quad_bcast<2>(r1), S2 = fe_quad_bcast<3>(r1);
+  const Fe P = F::sub(U2, U1), R = F::sub(S2, S1);
+  if (F::is_zero(P)) {
+    if (F::is_zero(R)) return E::dbl(a);
+    return E::identity();
+  }
+  const Fe r2 = F::mul(fe_sel4(q, P, R, a.zz, a.zzz), fe_sel4(q, P, R, b.zz, b.zzz));
+  const Fe PP = fe_quad_bcast<0>(r2), RR = fe_quad_bcast<1>(r2);
+  const Fe r3 = F::mul(fe_sel4(q, P, U1, r2, P), PP);
+  const Fe PPP = fe_quad_bcast<0>(r3), Q = fe_quad_bcast<1>(r3);
+  Xyzz c;
+  c.zz = fe_quad_bcast<2>(r3);
+  c.x = F::carry(F::sub(F::sub(F::sub(RR, PPP), Q), Q));
+  const Fe QX = F::sub(Q, c.x);
+  const Fe r4 = F::mul(fe_sel4(q, R, S1, R, r2), fe_sel4(q, QX, PPP, QX, PPP));
+  c.y = F::carry(F::sub(fe_quad_bcast<0>(r4), fe_quad_bcast<1>(r4)));
+  c.zzz = fe_quad_bcast<3>(r4);
+  c.inf = false;
+  return c;
+}
+
+// lane l takes the value of lane src(l) (any lane map; LDS crossbar)
+template <int BF>
+__device__ __forceinline__ Xyzz xyzz_from_lane(const Xyzz& a, int src) {
+  Xyzz o;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    o.x.l[i] = __shfl(a.x.l[i], src, 64);
+    o.y.l[i] = __shfl(a.y.l[i], src, 64);
+    o.zz.l[i] = __shfl(a.zz.l[i], src, 64);
+    o.zzz.l[i] = __shfl(a.zzz.l[i], src, 64);
+  }
+  o.inf = __shfl((int)a.inf, src, 64) != 0;
+  return o;
+}
+// Sum of the values held by lanes [0, cnt) of a wave (cnt a power of two, wave-uniform); the result is valid in lanes 0..3.
+// Levels with more than sixteen additions run one addition per lane (Ec::add); then value j moves to quad j and the
+// remaining levels -- at most sixteen additions, four lanes each -- run quad-cooperatively.  Every lane must call.
+template <int BF>
+__device__ __forceinline__ Xyzz tree_sum_quad(Xyzz v, int cnt) {
+  using E = Ec<BF>;
+  const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll 1
+  while (cnt > 16) {
+    cnt >>= 1;
+    v = E::add(v, xyzz_from_lane<BF>(v, lane + cnt < 64 ? lane + cnt : lane));
+  }
+  v = xyzz_from_lane<BF>(v, lane >> 2);
+#pragma unroll 1
+  for (int off = 2 * cnt; off >= 4; off >>= 1) v = quad_add<BF>(v, xyzz_from_lane<BF>(v, lane + off < 64 ? lane + off : lane));
+  return v;
+}
+
 // Bucket accumulation.  BF = base field id.  Persistent waves: the grid is sized to the chip
 // (2 waves per SIMD) and every wave pulls work items from a shared counter until none is left
 // (bounded loop; every wave reaches item >= total and leaves).  Items, longest first:
@@ -637,6 +726,27 @@ __global__ void __launch_bounds__(256) k_reduce1(const uint32_t* __restrict__ bs
   IO::store_dev_xyzz(partial + 64ull * r + 32, running);
 }
 
+// k_reduce1 for few runs (a small MSM): one QUAD per run, the chain of 2 S additions runs at the quad-cooperative latency.
+template <int BF>
+__global__ void __launch_bounds__(256) k_reduce1_quad(const uint32_t* __restrict__ bsum, uint32_t* __restrict__ partial,
+                                                      uint32_t nruns, int s) {
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (r >= nruns) return;  // whole quads leave together
+  const uint32_t S = 1u << s, first = r << s;
+  Xyzz running = E::identity(), total = E::identity();
+  for (int k = (int)S - 1; k >= 0; k--) {
+    const Xyzz bk = IO::load_dev_xyzz(bsum + 32ull * (first + k));  // the four lanes read the same words
+    running = quad_add<BF>(running, bk);
+    total = quad_add<BF>(total, running);
+  }
+  if ((threadIdx.x & 3u) == 0) {
+    IO::store_dev_xyzz(partial + 64ull * r, total);
+    IO::store_dev_xyzz(partial + 64ull * r + 32, running);
+  }
+}
+
 // grid = (2 + nbits, windows, ceil(slices / 4)); components 0 and 1 = the two halves of P, component
 // 2+i = U_i.  A component sums per/2 values; it is cut into `slices` slices, one wave each: lanes
 // first (every lane busy), then the wave, then the (up to) four waves of the workgroup through LDS --
@@ -674,7 +784,7 @@ __global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ pa
       }
     }
   }
-  acc = wave_sum_xyzz<BF>(acc);
+  acc = tree_sum_quad<BF>(acc, 64);
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
@@ -698,7 +808,7 @@ __global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ pa
     }
     v.inf = xs[lane][36] != 0;
   }
-  v = wave_sum_xyzz<BF, 2>(v);
+  v = tree_sum_quad<BF>(v, 4);
   const uint64_t o = (uint64_t)w * gridDim.x + comp;
   if (lane == 0) {
     if (gridDim.z == 1)
@@ -720,7 +830,7 @@ __global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ pa
   __threadfence();
   Xyzz a = E::identity();
   if (lane < gridDim.z) a = IO::load_dev_xyzz(tmp + 32ull * (o * gridDim.z + lane));
-  a = group_sum_xyzz<BF>(a, (int)(gridDim.z >> 1));
+  a = tree_sum_quad<BF>(a, (int)gridDim.z);
   if (lane == 0) IO::store_ark_xyzz(out + 32ull * o, a);
 }
 
@@ -1947,8 +2057,9 @@ __global__ void __launch_bounds__(256) k_verify_scalars(const uint32_t* __restri
 // back into the caller's value array, so the 32-byte values are never reordered).  SPMV_GROUP lanes
 // share a row: R1CS rows hold a handful of entries, with a few long ones.  Scalars in ark form.
 // ---------------------------------------------------------------------------
-constexpr uint32_t SPMV_GROUP = 8;
-template <int SF>
+// GROUP = 8 for matrices with long rows; 2 when every row is short (the R1CS shape: a handful of entries a row -- with
+// eight lanes a row most lanes idle through the multiplication and the kernel is bound by its instruction issue).
+template <int SF, uint32_t SPMV_GROUP>
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx,
                                               const uint32_t* __restrict__ perm, const uint32_t* __restrict__ val,
                                               const uint32_t* __restrict__ vec, uint32_t* __restrict__ out, uint32_t n_rows) {
