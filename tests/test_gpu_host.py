@@ -212,3 +212,32 @@ def test_ipa_prove_verify_full_size_2_20(bp, c):
         bp.bp_verify_cached(gens, result, got, seed)
     finally:
         gens.free()
+
+
+def test_ipa_prove_large_unpadded_with_mixed_z(bp):
+    """The pipelined, two-phase generator upload of bpgpu_ipa_begin (first round computed while the second half of the
+    generators crosses PCIe; Z = 1 chunks compacted on the way) at a size that is NOT a power of two: n = 100 000 pads to
+    2^17 with identities, one chunk of A carries a Jacobian point with Z = 5 and another an identity (those chunks go up
+    uncompacted), and the proof must equal the oracle's on the explicitly padded, normalised inputs."""
+    c, cid, n = pm.PALLAS, 0, 100_000
+    A, B, q, a, b, seed = bp.ipa_inputs(cid, n)
+    A = A.copy()
+    ident = co.normalise(cid, np.zeros((1, 12), np.uint64))
+    x, y = H.jac_from_abi(c, A[70_000:70_001])[0]
+    A[70_000] = H.jac_abi(c, [(x * 25 % c.q, y * 125 % c.q, 5)])[0]   # same point, Z = 5
+    A[40_000] = ident[0]                                               # an identity among the generators
+    np_ = 1 << 17
+    An = A.copy()
+    An[70_000] = H.jac_abi(c, [(x, y)])[0]
+    pad_p = np.tile(ident, (np_ - n, 1))
+    zs = np.zeros((np_ - n, 4), np.uint64)
+    ls, rs, ch, fa, fb = co.bp_prove(cid, np.concatenate([An, pad_p]), np.concatenate([B, pad_p]), q,
+                                     np.concatenate([a, zs]), np.concatenate([b, zs]), seed, threads=16)
+    pf = bp.bp_prove(cid, A, B, q, a, b, seed)
+    assert (pf["ls"] == ls).all() and (pf["rs"] == rs).all() and (pf["challenges"] == ch).all()
+    assert (pf["final_a"] == fa).all() and (pf["final_b"] == fb).all()
+    # the host-to-host MSM goes through the same pipeline: Z = 5 and identity chunks against the all-normalised input
+    from bulletproofs_amd import ffi
+    assert (ffi.msm(cid, A, a) == ffi.msm(cid, An, a)).all()
+    want = co.msm_pippenger(cid, An, a, threads=16)
+    assert (ffi.msm(cid, A, a)[:8] == want[:8]).all()
