@@ -355,6 +355,19 @@ struct OpSpan {
   }
 };
 
+// Keeps the spans inside its scope from recording (the prover's short rounds: four event packets a round for timers
+// nobody reads there)
+struct OpMute {
+  Ctx& C;
+  bool on;
+  OpMute(Ctx& c, bool mute) : C(c), on(mute) {
+    if (on) C.op_depth++;
+  }
+  ~OpMute() {
+    if (on) C.op_depth--;
+  }
+};
+
 inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 int check_ready() {
@@ -534,9 +547,9 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const size_t lds_bytes = (size_t)sp.nbins * 4;
   if (lds_bytes > 64 * 1024) return fail(BPGPU_E_ARG, "window width %d needs %zu B of LDS bin counters", c, lds_bytes);
 
-  TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2 + 64 + 4096));  // bin_count | chunk counter | tickets | bin_cursor
+  // bin_count | chunk counter | tickets | bucket counts | bin_cursor: the first four are zeroed by ONE fill per MSM
+  TRY(C.counts.ensure((size_t)sp.nbins * BIN_PAD * 4 * 2 + 64 + 4096 + (size_t)NB * 4));
   TRY(C.cursor.ensure((size_t)(sp.nbins + 1) * 4 * 2));      // bin_start | tile_start
-  TRY(C.bcount.ensure((size_t)NB * 4));
   TRY(C.offs.ensure((size_t)(NB + 1) * 4));
   TRY(C.order.ensure((size_t)NB * 4));
   TRY(C.canon.ensure((size_t)slots * W * 4));  // window-major digit words
@@ -556,7 +569,8 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   uint32_t* bin_count = C.counts.as<uint32_t>();
   uint32_t* chunk_counter = bin_count + (size_t)sp.nbins * BIN_PAD;  // zeroed with bin_count
   uint32_t* red_tickets = chunk_counter + 16;  // k_reduce2: workgroups done per output (1024 words, zeroed with bin_count)
-  uint32_t* bin_cursor = red_tickets + 1024;
+  uint32_t* bcount = red_tickets + 1024;  // per bucket: entries (k_bin_count), then the placing cursor (k_bin_place)
+  uint32_t* bin_cursor = bcount + NB;
   // heavy-bucket lists: at most entries/HEAVY_T heavy buckets and entries/HEAVY_PIECE + that many pieces
   const uint64_t entries = slots * W;
   const uint64_t mean_len = entries / NB;
@@ -576,6 +590,9 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   int glog = 0;
   while (glog < 6 && (mean_len >> glog) > 12 && ((uint64_t)NB << (glog + 1)) <= lanes) glog++;
   const uint64_t lane_len = mean_len >> glog;  // entries a lane walks
+  // (Letting one lane walk lists up to a third of a lane's total work -- the 2^14 top-window buckets of a 2^24-point MSM,
+  // 512 entries each against a mean of 32, would then be plain chunks instead of wave pieces -- is slower: 14.5 against
+  // 13.7 ms of accumulation; the wave pieces stay.)
   const uint32_t heavy_t = (uint32_t)((4 * lane_len > floor_t ? 4 * lane_len : floor_t) << glog);
   const size_t max_heavy = (size_t)(entries / heavy_t) + 1, max_pieces = (size_t)(entries / HEAVY_PIECE) + max_heavy;
   TRY(C.heavy.ensure((3 * max_heavy + 2 * max_pieces + 32 * max_pieces) * 4));
@@ -593,30 +610,32 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   const uint32_t max_tiles = (uint32_t)(slots * W / BIN_TILE) + sp.nbins;
 
   hipStream_t st = C.stream;
-  HIP_TRY(hipEventRecord(C.ev[0], st));
-  HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4 + 64 + 4096, st));
+  // the phase timers (bpgpu_last_msm_timings) cost five event packets; the prover's short rounds (table mode, 0.25 ms of
+  // kernels) go without them: about 0.2 ms per 2^20 proof
+  const bool phase_events = !table;  // (on a 2^20-point MSM the five packets are 15-20 us of 1470: kept, the bench reads them)
+  if (phase_events) HIP_TRY(hipEventRecord(C.ev[0], st));
+  HIP_TRY(hipMemsetAsync(bin_count, 0, (size_t)sp.nbins * BIN_PAD * 4 + 64 + 4096 + (size_t)NB * 4, st));
   k_part_count<SF><<<part_grid, 1024, lds_bytes, st>>>(plan, sp, d_scalars, C.canon.as<uint32_t>(), bin_count);
-  HIP_TRY(hipEventRecord(C.ev[1], st));
+  if (phase_events) HIP_TRY(hipEventRecord(C.ev[1], st));
   k_bin_scan<<<1, 1024, 0, st>>>(bin_count, bin_start, tile_start, bin_cursor, sp.nbins, d_entries);
   k_part_scatter<<<dim3(cdiv(plan.n, PART_TILE), plan.M * W), 1024, 0, st>>>(
       plan, sp, C.canon.as<uint32_t>(), bin_start, bin_cursor, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>());
-  HIP_TRY(hipEventRecord(C.ev[2], st));
-  HIP_TRY(hipMemsetAsync(C.bcount.p, 0, (size_t)NB * 4, st));
-  k_bin_count<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_fine.as<uint16_t>(), C.bcount.as<uint32_t>());
-  k_bin_offsets<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, C.bcount.as<uint32_t>(), C.offs.as<uint32_t>(),
+  if (phase_events) HIP_TRY(hipEventRecord(C.ev[2], st));
+  k_bin_count<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_fine.as<uint16_t>(), bcount);
+  k_bin_offsets<<<sp.nbins, 1024, 0, st>>>(sp, bin_start, bcount, C.offs.as<uint32_t>(),
                                            C.order.as<uint32_t>(), hv);
   k_bin_place<<<max_tiles, 1024, 0, st>>>(sp, bin_start, tile_start, C.ent_idx.as<uint32_t>(), C.ent_fine.as<uint16_t>(),
-                                          C.offs.as<uint32_t>(), C.bcount.as<uint32_t>(), C.sorted.as<uint32_t>());
+                                          C.offs.as<uint32_t>(), bcount, C.sorted.as<uint32_t>());
   if (points_ready) TRY((*points_ready)());
-  HIP_TRY(hipEventRecord(C.ev[3], st));
+  if (phase_events) HIP_TRY(hipEventRecord(C.ev[3], st));
   k_accum<BF><<<C.num_cus * accum_waves, 256, 0, st>>>(d_points, C.offs.as<uint32_t>(), C.sorted.as<uint32_t>(),
                                              C.order.as<uint32_t>(), C.bsum.as<uint32_t>(), NB, sp.nbins, sp.fine_bits, hv,
                                              chunk_counter, glog);
   k_heavy_merge<BF><<<C.num_cus, 256, 0, st>>>(hv, C.bsum.as<uint32_t>());
-  HIP_TRY(hipEventRecord(C.ev[4], st));
+  if (!table) HIP_TRY(hipEventRecord(C.ev[4], st));
   // few runs (fewer quads than the chip has lanes at two waves a SIMD): the chain of 2 S additions per run is what the
   // stage takes, so a quad shares each addition (kernels.cuh, quad_add); many runs: one lane each, bound by throughput
-  if ((uint64_t)nruns * 4 <= (uint64_t)C.num_cus * 4 * 64 * 2 + 8192 && !getenv("BPGPU_NO_QUAD"))
+  if ((uint64_t)nruns * 4 <= (uint64_t)C.num_cus * 4 * 64 * 2 + 8192)
     k_reduce1_quad<BF><<<cdiv((uint64_t)nruns * 4, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
   else
     k_reduce1<BF><<<cdiv(nruns, 256), 256, 0, st>>>(C.bsum.as<uint32_t>(), C.partial.as<uint32_t>(), nruns, s);
@@ -625,8 +644,8 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     // slice pays a 6-step wave tree on top of its lanes' sums, so more, shorter slices cost more additions
     const uint32_t outputs = (uint32_t)(comps * plan.M * Wb), half = runs_per_window >> 1;
     uint32_t slices = 1;
-    static const uint32_t r2_waves = getenv("BPGPU_R2_WAVES") ? (uint32_t)atoi(getenv("BPGPU_R2_WAVES")) : 1024u;
-    while (slices < 64 && 2 * slices * outputs <= r2_waves && 2 * slices * 64 <= half) slices *= 2;
+    // (2048 / 4096 / 8192 waves measured again with the quad-cooperative trees of round 3: slower at every size, 2^14 .. 2^20)
+    while (slices < 64 && 2 * slices * outputs <= 1024 && 2 * slices * 64 <= half) slices *= 2;
     const uint32_t groups = cdiv(slices, 4);  // a workgroup adds up its four slices itself
     // More than one workgroup per output (the prover's short rounds): the last one to finish adds up all of them --
     // its addition code is warm, where a third kernel for two additions spent 39 us on a launch and cold fetches.
@@ -637,7 +656,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     k_reduce2<BF><<<dim3(comps, plan.M * Wb, groups), 256, 0, st>>>(
         C.partial.as<uint32_t>(), C.redtmp.as<uint32_t>(), d_winsum, runs_per_window, slices, fused ? red_tickets : nullptr);
   }
-  HIP_TRY(hipEventRecord(C.ev[5], st));
+  if (phase_events) HIP_TRY(hipEventRecord(C.ev[5], st));
   // Horner tail on up to four host threads (the context's pool workers and this one): a batch of two MSMs gives each
   // MSM half of them, a single MSM all.  Share g of an MSM takes the windows [g W / G, (g+1) W / G) and
   // runs its doublings down to bit position 0, so the shares simply add up; the critical path is the 255
@@ -657,9 +676,12 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
       part[k] = horner<BF>(hw + m * stride, Wb, c, s, nbits, g * Wb / G, (g + 1) * Wb / G);
     }
   };
-  HIP_TRY(hipEventSynchronize(C.ev[4]));
+  // Table mode (the prover's short rounds): the tail is a dozen additions per MSM and no doublings -- the calling thread
+  // does it alone, without the event, the wake-up and the spinning workers
+  const bool solo = table;
+  if (!solo) HIP_TRY(hipEventSynchronize(C.ev[4]));
   std::atomic<int> go{0};  // 0: wait, 1: the window sums are in host memory, -1: give up
-  C.hpool.begin([&](int w) {
+  if (!solo) C.hpool.begin([&](int w) {
     const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
     uint32_t looks = 0;
     while (go.load(std::memory_order_acquire) == 0) {
@@ -674,7 +696,7 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   if (sync_err == hipSuccess) sync_err = hipGetLastError();
   if (sync_err != hipSuccess) {
     go.store(-1, std::memory_order_release);
-    C.hpool.wait();
+    if (!solo) C.hpool.wait();
     return fail(BPGPU_E_HIP, "MSM kernels failed: %s", hipGetErrorString(sync_err));
   }
   {
@@ -684,8 +706,12 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   }
   auto t0 = std::chrono::steady_clock::now();
   go.store(1, std::memory_order_release);
-  task(0);
-  C.hpool.wait();
+  if (solo) {
+    for (int t = 0; t < T; t++) task(t);
+  } else {
+    task(0);
+    C.hpool.wait();
+  }
   for (int m = 0; m < plan.M; m++) {
     host::HPoint<BF> total = part[m * G];
     for (int g = 1; g < G; g++) total = host::HEc<BF>::add(total, part[m * G + g]);
@@ -693,7 +719,9 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   }
   auto t1 = std::chrono::steady_clock::now();
   C.msm_ms[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-  C.msm_timed = true;  // the GPU phases are read off the events when bpgpu_last_msm_timings asks
+  C.msm_timed = phase_events;  // the GPU phases are read off the events when bpgpu_last_msm_timings asks
+  if (!phase_events)
+    for (int i : {0, 1, 2, 3, 5, 7}) C.msm_ms[i] = 0;
   return 0;
 }
 
@@ -2603,6 +2631,7 @@ int bpgpu_ipa_round_lr(bpgpu_ipa* s, uint64_t l_xy_inf[9], uint64_t r_xy_inf[9])
   TRY(ipa_usable(s));
   if (s->len <= 1) return fail(BPGPU_E_STATE, "the vectors already have length 1");
   if (s->lr_done) return fail(BPGPU_E_STATE, "round_fold must follow round_lr");
+  OpMute mute(cx(), s->frozen && !s->lazy);
   const uint32_t n = (uint32_t)(s->len / 2), np = (uint32_t)s->np;
   if (s->lr_cached) {  // the first round of a large session: computed by bpgpu_ipa_begin
     memcpy(l_xy_inf, s->l_cache, 72);
@@ -2685,6 +2714,7 @@ int bpgpu_ipa_round_fold(bpgpu_ipa* s, const uint64_t x[4], const uint64_t x_inv
   TRY(check_ready());
   TRY(ipa_usable(s));
   if (!s->lr_done) return fail(BPGPU_E_STATE, "round_lr must precede round_fold");
+  OpMute mute(cx(), s->frozen && !s->lazy);
   const uint32_t n = (uint32_t)(s->len / 2), np = (uint32_t)s->np;
   // a' = x a_lo + x^-1 a_hi;  b' = x^-1 b_lo + x b_hi          (bp_iter.rs:88-95)
   FoldScalars fa = make_fold_scalars(x, x_inv), fb = make_fold_scalars(x_inv, x);

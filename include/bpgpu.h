@@ -298,7 +298,8 @@ int bpgpu_points_sum(int curve, const uint64_t* xy_inf, size_t count, uint64_t o
  * context (whichever thread made it), measured with HIP events on the library's stream:
  * [0] digits + coarse histogram, [1] bin scan + scatter to bins, [2] sort inside bins,
  * [3] bucket accumulation (k_accum + k_heavy_merge), [4] unused, [5] bucket reduction,
- * [6] host tail (wall), [7] total GPU. */
+ * [6] host tail (wall), [7] total GPU.  The MSMs of an IPA session's short rounds (fixed-base table mode) record no
+ * phase events: after one of them the GPU entries read 0. */
 int bpgpu_last_msm_timings(float out_ms[8]);
 /* Number of (point, window) pairs with a non-zero digit in the last bpgpu_msm* call (a batch counts both
  * of its MSMs): the additions the bucket accumulation performed, which bench.py prices the kernel with. */
