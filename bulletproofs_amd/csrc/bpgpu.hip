@@ -481,6 +481,7 @@ int choose_window(uint32_t n, int M) {
   static const int8_t measured[9] = {15, 15, 16, 16, 17, 17, 17, 19, 20};
   if (lg == 18 && M > 1) return 15;  // a batch of two doubles the buckets to reduce: one bit narrower (1.22 -> 1.16 ms)
   if (lg >= 16 && lg <= 24) return measured[lg - 16];
+  if (lg == 14 && M == 1) return 13;  // 14 leaves a three-bit top window: 0.51 ms against 0.44 at 13 (and 0.45 at 15)
   if (lg >= 5 && lg <= 15) return M > 1 ? lg - 2 : lg;
   int c = lg - 4;
   if (c < 2) c = 2;
@@ -594,10 +595,16 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
   // 512 entries each against a mean of 32, would then be plain chunks instead of wave pieces -- is slower: 14.5 against
   // 13.7 ms of accumulation; the wave pieces stay.)
   const uint32_t heavy_t = (uint32_t)((4 * lane_len > floor_t ? 4 * lane_len : floor_t) << glog);
-  const size_t max_heavy = (size_t)(entries / heavy_t) + 1, max_pieces = (size_t)(entries / HEAVY_PIECE) + max_heavy;
+  // a wave-piece gives its lanes about as many entries as an ordinary lane walks (a piece of 1024 in an MSM whose lanes
+  // walk four entries each was the longest item of the kernel by a factor of three: the sparse top window of any width
+  // that does not divide 255 cost 0.15 ms at 2^16 points)
+  uint32_t piece_len = (uint32_t)(64 * (mean_len < 4 ? 4 : (mean_len > 16 ? 16 : mean_len)));
+  if (piece_len > HEAVY_PIECE_MAX) piece_len = HEAVY_PIECE_MAX;
+  const size_t max_heavy = (size_t)(entries / heavy_t) + 1, max_pieces = (size_t)(entries / piece_len) + max_heavy;
   TRY(C.heavy.ensure((3 * max_heavy + 2 * max_pieces + 32 * max_pieces) * 4));
   HeavyLists hv;
   hv.threshold = heavy_t;
+  hv.piece = piece_len;
   hv.counters = chunk_counter + 4;
   hv.bucket = C.heavy.as<uint32_t>();
   hv.piece0 = hv.bucket + max_heavy;

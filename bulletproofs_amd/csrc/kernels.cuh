@@ -60,9 +60,10 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t (&w)[8], int pos
 //   k_bin_count / k_bin_offsets / k_bin_place   counting sort of each bin by fine bucket -> sorted[], offs[]
 // ---------------------------------------------------------------------------
 constexpr uint32_t HEAVY_T_MIN = 128;   // a single lane never walks a list longer than max(this, 4 x the mean)
-constexpr uint32_t HEAVY_PIECE = 1024;  // entries per wave-piece of a heavy bucket
+constexpr uint32_t HEAVY_PIECE_MAX = 1024;  // most entries per wave-piece of a heavy bucket (HeavyLists::piece)
 struct HeavyLists {
   uint32_t threshold;  // lists longer than this are heavy
+  uint32_t piece;      // entries per wave-piece: 64 lanes x about the entries an ordinary lane walks (256 .. HEAVY_PIECE_MAX)
   uint32_t* counters;  // [0] heavy buckets, [1] pieces, [2] piece work counter (all zeroed per MSM)
   uint32_t* bucket;    // per heavy bucket: bucket id
   uint32_t* piece0;    //                   first piece
@@ -358,15 +359,15 @@ __global__ void __launch_bounds__(1024) k_bin_offsets(SortPlan sp, const uint32_
   // a bucket with more than hv.threshold entries is cut into pieces of HEAVY_PIECE entries that whole
   // waves accumulate; single lanes skip it
   if (tid < F && mine > hv.threshold) {
-    uint32_t np = (mine + HEAVY_PIECE - 1) / HEAVY_PIECE;
+    uint32_t np = (mine + hv.piece - 1) / hv.piece;
     uint32_t h = atomicAdd(&hv.counters[0], 1u);
     uint32_t p0 = atomicAdd(&hv.counters[1], np);
     hv.bucket[h] = bin * F + tid;
     hv.piece0[h] = p0;
     hv.npieces[h] = np;
     for (uint32_t i = 0; i < np; i++) {
-      uint32_t lo = start + i * HEAVY_PIECE;
-      uint32_t hi = lo + HEAVY_PIECE < start + mine ? lo + HEAVY_PIECE : start + mine;
+      uint32_t lo = start + i * hv.piece;
+      uint32_t hi = lo + hv.piece < start + mine ? lo + hv.piece : start + mine;
       hv.piece_lo[p0 + i] = lo;
       hv.piece_hi[p0 + i] = hi;
     }
@@ -589,7 +590,7 @@ __device__ __forceinline__ Xyzz tree_sum_quad(Xyzz v, int cnt) {
 // (bounded loop; every wave reaches item >= total and leaves).  Items, longest first:
 //   * the pieces of heavy buckets (skewed scalars, or the top window whose few significant bits
 //     leave it a handful of buckets): the 64 lanes stride through <= HEAVY_PIECE entries and
-//     their partial sums are combined across the wave -> psum[piece];
+//     their partial sums are combined across the wave (tree_sum_quad) -> psum[piece];
 //   * chunks of 64 ordinary buckets, one per lane: chunk k is the (k / nbins)-th group of 64
 //     buckets, in decreasing size, of bin k % nbins (k_bin_offsets' order[]), so lanes of a wave
 //     walk lists of near-equal length and the kernel's tail is made of the shortest lists.
@@ -672,7 +673,7 @@ __global__ void __launch_bounds__(256, BP_ACCUM_WAVES) k_accum(const uint32_t* _
       ent_n = ent_nn;
     }
     if (piece) {  // wave-uniform
-      acc = wave_sum_xyzz<BF>(acc);
+      acc = tree_sum_quad<BF>(acc, 64);
       if (lane == 0) IO::store_dev_xyzz(hv.psum + 32ull * k, acc);
     } else {
       if (glog) acc = group_sum_xyzz<BF>(acc, 1 << (glog - 1));  // wave-uniform; every lane takes part
@@ -693,7 +694,7 @@ __global__ void __launch_bounds__(256, 2) k_heavy_merge(HeavyLists hv, uint32_t*
     const uint32_t p0 = hv.piece0[h], np = hv.npieces[h];
     Xyzz acc = E::identity();
     for (uint32_t i = lane; i < np; i += 64) acc = E::add(acc, IO::load_dev_xyzz(hv.psum + 32ull * (p0 + i)));
-    acc = wave_sum_xyzz<BF>(acc);
+    acc = tree_sum_quad<BF>(acc, 64);
     if (lane == 0) IO::store_dev_xyzz(bsum + 32ull * hv.bucket[h], acc);
   }
 }

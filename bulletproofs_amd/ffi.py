@@ -462,6 +462,8 @@ def auto_window_bits(n: int) -> int:
     lg = max(0, int(n).bit_length() - 1)
     if 16 <= lg <= 24:
         return (15, 15, 16, 16, 17, 17, 17, 19, 20)[lg - 16]   # measured optimum (choose_window's table)
+    if lg == 14:
+        return 13
     if 5 <= lg <= 15:
         return lg
     return min(20, max(2, lg - 4))
