@@ -475,14 +475,24 @@ def next_rows_leg(ffi, curve, mad_peak):
     for _ in range(3):
         ffi.fold_points_kary_device(curve, d_g, ck, k, y, d_o)
         best = min(best, ffi.last_op_ms())
-    outputs, dbls, adds, _kind = ffi.last_fold_ops()  # the last of the k - 1 launches; all share one multiplier
-    yard = (k - 1) * (dbls * MULS_PER_DOUBLE + adds * MULS_PER_MIXED_ADD) * MADS_PER_FIELD_MUL
-    execd = (k - 1) * (dbls * EXEC_MADS_JAC_DOUBLE + adds * EXEC_MADS_JAC_MIXED_ADD)
-    out["fold_points_kary"] = {"bound": "valu", "ck": ck, "k": k, "launches": k - 1, "kernel_ms": best,
-                               "outputs_per_s": ck / (best * 1e-3), "achieved": yard / (best * 1e-3) / 1e12, "peak": mad_peak / 1e12,
+    outputs, dbls, adds, kind = ffi.last_fold_ops()  # group operations of the whole call
+    assert kind == 3, "unexpected fold kernel"
+    yard = (dbls * MULS_PER_DOUBLE + adds * MULS_PER_MIXED_ADD) * MADS_PER_FIELD_MUL
+    execd = dbls * EXEC_MADS_JAC_DOUBLE + adds * EXEC_MADS_JAC_MIXED_ADD
+    # the reference's schedule for the same outputs: k - 1 scalar multiplications by double-and-add (mul of a 255-bit
+    # power of x: 255 doublings + 127.5 additions) and k - 1 additions per output (scale_vec + sum_vecs, util/mod.rs:25-55)
+    yard_ref = ck * (k - 1) * (255 * MULS_PER_DOUBLE + 128.5 * MULS_PER_MIXED_ADD) * MADS_PER_FIELD_MUL
+    out["fold_points_kary"] = {"bound": "valu", "ck": ck, "k": k, "launches": -(-(k - 1) // 7), "kernel_ms": best,
+                               "outputs_per_s": ck / (best * 1e-3), "doublings_per_output": dbls / outputs,
+                               "mixed_additions_per_output": adds / outputs,
+                               "achieved": yard / (best * 1e-3) / 1e12, "peak": mad_peak / 1e12,
                                "unit": "Tmad/s", "frac": yard / (best * 1e-3) / mad_peak, "frac_executed": execd / (best * 1e-3) / mad_peak,
-                               "note": "y = powers(x, 0..k): Horner's rule, k - 1 launches of k_fold_monic over ck outputs (one wave per "
-                                       "SIMD at this size: latency-bound); group operations as executed (bpgpu_last_fold_ops)"}
+                               "frac_reference_schedule": yard_ref / (best * 1e-3) / mad_peak,
+                               "note": "y = powers(x, 0..k): the k - 1 shared multipliers ride ONE doubling chain (k_fold_multi, operands "
+                                       "in global memory, one wave per SIMD at this size: latency-bound); frac / frac_executed price the "
+                                       "group operations the call executed (bpgpu_last_fold_ops) by the SURVEY yardstick / the compiled "
+                                       "Jacobian counts; frac_reference_schedule prices the reference's k - 1 double-and-add "
+                                       "multiplications per output against the same time"}
     d_g.free()
     d_o.free()
     # k-ary scalar fold (ipa_to_bp_unroll.rs:248-252): ck = 2^20, k = 8: 32 (k + 1) B per output

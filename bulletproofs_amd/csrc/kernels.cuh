@@ -1489,6 +1489,103 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
 }
 
 // ---------------------------------------------------------------------------
+// Up to MULTI_MAX_M shared multipliers on ONE doubling chain:
+//   o[i] = [p[i] +] s_0 q[i] + s_1 q[n + i] + ... + s_{m-1} q[(m-1) n + i],   i < n
+// -- the k-ary fold sum_vecs(chunks.zip(y).map(scale_vec)) of src/proofs/bp_rec_kary.rs:105-112 ==
+// src/reductions/ipa_to_bp_unroll.rs:253-260 in one pass (k - 1 <= 7 multipliers and chunk 0 as p when y[0] = 1).
+// Horner's rule over k_fold_monic walks k - 1 chains of ~128 doublings + ~55 additions one after the other; here
+// one chain of ~128 doublings carries all the additions (7 multipliers: 128 + 385 group operations instead of 1281),
+// and where the launch is a wave per SIMD (ck <= 2^16) the time follows the chain's length.
+// The operands do not fit registers or LDS (7 generators and their alpha-multiples are 28 field elements a lane), so
+// they stay in GLOBAL memory: the kernel first writes Q'_t = alpha Q_t (one affine addition each, ONE workgroup-shared
+// inversion for all of a lane's generators) to `alpha`, then walks a host-made list of operations -- "d doublings,
+// then add the point of digit code c of generator t" -- and loads the operand of the NEXT operation while the
+// current one runs (a lane reads only its own column: coalesced 64-byte rows; 2 ms of arithmetic hide the latency).
+// o may alias p; o and alpha must not overlap q.
+// ---------------------------------------------------------------------------
+constexpr int MULTI_MAX_M = 7;
+constexpr int MULTI_MAX_OPS = 768;
+// op: bits 0-3 digit code (as in MonicPlan), 4-6 generator t, 7-11 doublings before the addition, 12 an addition follows
+struct MultiOps {
+  uint16_t op[MULTI_MAX_OPS];
+  uint32_t nops;
+  uint32_t m;
+};
+template <int BF>
+__global__ void __launch_bounds__(256) k_fold_multi(const uint32_t* __restrict__ q, const uint32_t* p, uint32_t* __restrict__ alpha,
+                                                    uint32_t* o, const MultiOps ops, uint32_t n) {
+  using F = Fp<BF>;
+  using E = Ec<BF>;
+  using IO = PointIo<BF>;
+  __shared__ uint32_t tree[512][9];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n;
+  const int m = (int)ops.m;  // wave-uniform
+  const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
+  const Fe zeta2 = F::sqr(zeta);
+  {
+    // Q'_t = Q_t - phi(Q_t) for every generator of the lane: prefix products of the slopes' denominators, one inversion
+    Fe pre[MULTI_MAX_M];
+    Fe run = F::one();
+#pragma unroll
+    for (int t = 0; t < MULTI_MAX_M; t++) {
+      pre[t] = run;
+      if (t < m && active) {
+        const Aff Q = IO::load_dev_affine(q + 16ull * ((uint64_t)t * n + i));
+        if (!Q.inf) run = F::mul(run, alpha_den<BF>(Q, zeta));
+      }
+    }
+    Fe inv = block_inverse_256<BF>(run, tree);
+#pragma unroll
+    for (int t = MULTI_MAX_M - 1; t >= 0; t--) {
+      if (t < m && active) {
+        const Aff Q = IO::load_dev_affine(q + 16ull * ((uint64_t)t * n + i));
+        Aff A;
+        A.inf = true;
+        A.x = A.y = F::zero();
+        if (!Q.inf) {
+          const Fe it = F::mul(inv, pre[t]);
+          inv = F::mul(inv, alpha_den<BF>(Q, zeta));
+          A = alpha_point<BF>(Q, it, zeta2);
+        }
+        IO::store_dev_affine(alpha + 16ull * ((uint64_t)t * n + i), A);  // read back by this lane only
+      }
+    }
+  }
+  Jac acc = E::jidentity();
+  if (active && ops.nops) {
+    auto operand = [&](uint32_t op) -> const uint4* {
+      const uint32_t t = (op >> 4) & 7u;
+      return reinterpret_cast<const uint4*>(((op & 4u) ? alpha : q) + 16ull * ((uint64_t)t * n + i));
+    };
+    const uint4* pp = operand(ops.op[0]);
+    uint4 r0 = pp[0], r1 = pp[1], r2 = pp[2], r3 = pp[3];
+    for (uint32_t j = 0; j < ops.nops; j++) {
+      const uint32_t op = ops.op[j];  // wave-uniform
+      pp = operand(ops.op[j + 1 < ops.nops ? j + 1 : j]);
+      const uint4 n0 = pp[0], n1 = pp[1], n2 = pp[2], n3 = pp[3];
+      for (uint32_t d = (op >> 7) & 31u; d > 0; d--) acc = E::jdbl(acc);
+      if (op & 0x1000u) {
+        uint32_t w[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+        Aff pt = IO::load_dev_affine(w);
+        const uint32_t sel = op & 3u;
+        if (sel != 1) pt.x = F::mul(pt.x, sel == 2 ? zeta : zeta2);
+        if (op & 8u) pt.y = F::carry(F::neg(pt.y));
+        E::jmadd(acc, pt);  // skips an identity operand (zero padding)
+      }
+      r0 = n0;
+      r1 = n1;
+      r2 = n2;
+      r3 = n3;
+    }
+  }
+  if (active && p) E::jmadd(acc, IO::load_dev_affine(p + 16ull * i));
+  const bool fin = active && !acc.inf;
+  const Fe inv = block_inverse_256<BF>(fin ? acc.z : F::one(), tree);
+  if (active) IO::store_dev_affine(o + 16ull * i, E::jto_affine_with(acc, inv));
+}
+
+// ---------------------------------------------------------------------------
 // Two fold rounds in one pass:  out[i] = g[i] + s1 g[i+q] + s2 g[i+2q] + s3 g[i+3q],  i < q.
 // The prover (bpgpu.hip, "pair folding") skips the generator fold of every other long round -- that
 // round's L and R are MSMs over the unfolded generators with weighted scalars, as in the deferred

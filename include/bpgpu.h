@@ -150,7 +150,9 @@ int bpgpu_fold_points_device(int curve, const void* d_g, size_t n_out, const uin
  * the vector to k*ck (zero_pad_to_multiple / zero_intersperse_to_multiple).  k = 1 is scale_vec,
  * y = (1, ..., 1) is sum_vecs, k = 0 gives zeros / identities (sum_vecs of nothing).  y: k scalars,
  * host memory.  Scalars: k <= 1024; `out` may alias `v`.  Points: jacobian in, jacobian Z = 1 out;
- * when y = (1, r, r^2, ...) (the reference always passes powers(x, 0..k)) Horner's rule is used. */
+ * with three chunks or more the multipliers share one doubling chain, seven at a time (chunk 0 is simply
+ * added when y[0] = 1, as in the reference's powers(x, 0..k)); bpgpu_last_fold_ops reports the group
+ * operations of the whole call. */
 int bpgpu_fold_scalars_kary(int curve, const uint64_t* v, size_t ck, size_t k, const uint64_t* y,
                             uint64_t* out);
 int bpgpu_fold_points_kary(int curve, const uint64_t* g_xyz, size_t ck, size_t k, const uint64_t* y,

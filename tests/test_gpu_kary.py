@@ -91,6 +91,19 @@ def test_fold_points_kary_small(ffi, c):
             want = [pm.jac_to_affine(c, p) for p in pm.fold_points_kary(c, [pm.to_jac(p) for p in g], k, y)]
             got = H.jac_from_abi(c, ffi.fold_points_kary(cid, H.jac_abi(c, g), k, H.scalars_abi(c, y)))
             assert got == want, (k, ck, y[:2])
+    # edge multipliers on the shared chain: -1, 0, 1, the cube roots of unity (GLV halves (0, +-1)), 2, -2; every chunk the
+    # same point (the chain adds a point to its own multiple) and an all-identity chunk
+    lam = next(pow(gg, (c.r - 1) // 3, c.r) for gg in range(2, 50) if pow(gg, (c.r - 1) // 3, c.r) != 1)
+    y = [c.r - 1, 0, 1, lam, lam * lam % c.r, 2, c.r - 2, c.r - lam]
+    k, ck = len(y), 3
+    g = H.rand_points(c, k * ck, 977)
+    for j in range(1, k):
+        g[j * ck] = g[0]
+    g[2 * ck:3 * ck] = [None] * ck
+    for yy in (y, [1] + y[1:]):
+        want = [pm.jac_to_affine(c, p) for p in pm.fold_points_kary(c, [pm.to_jac(p) for p in g], k, yy)]
+        got = H.jac_from_abi(c, ffi.fold_points_kary(cid, H.jac_abi(c, g), k, H.scalars_abi(c, yy)))
+        assert got == want
     # sum_vecs of nothing: identities
     assert ffi.fold_points_kary(cid, np.zeros((0, 12), np.uint64), 0, np.zeros((0, 4), np.uint64)).shape == (0, 12)
 
@@ -101,7 +114,8 @@ def test_fold_points_kary_and_hadamard_gp_vs_c_oracle(ffi, c):
     pts, sc = co.msm_bench_inputs(cid, 8 * 300)
     x = sc[0]
     xi = co.scalar_inverse(cid, x)
-    for k, ck in [(8, 300), (3, 257), (12, 200)]:
+    # (k = 12: two launches of the shared-chain fold, 7 + 4 multipliers; k = 17 with arbitrary y: 7 + 7 + 3)
+    for k, ck in [(8, 300), (3, 257), (12, 200), (17, 140)]:
         g = pts[:k * ck].copy()
         g[5] = co.normalise(cid, np.zeros((1, 12), np.uint64))[0]      # identity (zero_pad_to_multiple)
         for y in (co.powers(cid, xi, 0, k), sc[10:10 + k]):

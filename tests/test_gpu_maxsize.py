@@ -73,7 +73,34 @@ def test_msm_at_the_size_limit(ffi, curve, n):
         d_sc.free()
 
 
+def test_ipa_at_the_size_limit(ffi):
+    """Bp::prove / Bp::verify at BPGPU_IPA_MAX_N = 2^26 elements per vector, through the host-vector entry points (two-phase
+    generator upload, first round inside bpgpu_ipa_begin, batches of two MSMs over 2^26 + 1 slots).  The check is the
+    reference's own (src/proofs/bp_iter.rs:130-178): the verifier's single MSM over the ORIGINAL generators accepts the
+    proof and rejects a tampered one."""
+    from bulletproofs_amd import ark_bp
+    curve, n = 0, 1 << 26
+    d_pts, d_sc = grow_inputs(ffi, curve, 2 * n + 1, seed=21)
+    try:
+        pts = ffi.points_from_device(curve, d_pts, 2 * n + 1)
+        sc = d_sc.download(np.uint64, count=2 * n * 4).reshape(2 * n, 4)
+    finally:
+        d_pts.free()
+        d_sc.free()
+    A, B, q, a, b = pts[:n], pts[n:2 * n], pts[2 * n:], sc[:n], sc[n:]
+    result = ark_bp.commit(curve, A, B, q, a, b)
+    seed = b"ipa at the size limit".ljust(32, b"\0")
+    proof = ark_bp.bp_prove(curve, A, B, q, a, b, seed)
+    assert len(proof["ls"]) == len(proof["rs"]) == 26
+    ark_bp.bp_verify(curve, A, B, q, result, proof, seed)
+    bad = dict(proof, final_b=proof["final_b"].copy())
+    bad["final_b"][1] ^= np.uint64(4)
+    with pytest.raises(ark_bp.Panic):
+        ark_bp.bp_verify(curve, A, B, q, result, bad, seed)
+
+
 def test_one_point_beyond_the_limit_is_refused(ffi):
+    # (the IPA limit is checked the same way, without a GPU, in tests/test_abi.py)
     d = ffi.DeviceBuffer(64)
     try:
         with pytest.raises(ffi.BpGpuError):
