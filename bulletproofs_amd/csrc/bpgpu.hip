@@ -210,6 +210,7 @@ struct Uploader {
   int nt = T;
   void* buf[T][SLOTS] = {};
   hipStream_t ws[T] = {};
+  hipStream_t cs[T] = {};  // point uploads: the chunks' conversion kernels (ws carries the DMAs only, see pt_upload_begin)
   hipEvent_t ev[T][SLOTS] = {};
   hipEvent_t fence = nullptr, done[T] = {};
   hipEvent_t pdone[2][T] = {};  // point uploads (PtUpload): worker w has enqueued every chunk of phase p
@@ -224,6 +225,7 @@ struct Uploader {
     hipError_t e = hipEventCreateWithFlags(&fence, hipEventDisableTiming);
     for (int w = 0; w < nt && e == hipSuccess; w++) {
       e = hipStreamCreateWithFlags(&ws[w], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs[w], hipStreamNonBlocking);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&done[w], hipEventDisableTiming);
       for (int ph = 0; ph < 2 && e == hipSuccess; ph++) e = hipEventCreateWithFlags(&pdone[ph][w], hipEventDisableTiming);
       for (int k = 0; k < SLOTS && e == hipSuccess; k++) {
@@ -240,6 +242,7 @@ struct Uploader {
     pool.stop();
     for (int w = 0; w < T; w++) {
       if (ws[w]) (void)hipStreamSynchronize(ws[w]);
+      if (cs[w]) (void)hipStreamSynchronize(cs[w]);
       for (int k = 0; k < SLOTS; k++) {
         if (buf[w][k]) (void)hipHostFree(buf[w][k]);
         if (ev[w][k]) (void)hipEventDestroy(ev[w][k]);
@@ -252,8 +255,10 @@ struct Uploader {
         pdone[ph][w] = nullptr;
       }
       if (ws[w]) (void)hipStreamDestroy(ws[w]);
+      if (cs[w]) (void)hipStreamDestroy(cs[w]);
       done[w] = nullptr;
       ws[w] = nullptr;
+      cs[w] = nullptr;
     }
     if (fence) (void)hipEventDestroy(fence);
     fence = nullptr;
@@ -298,6 +303,19 @@ struct Ctx {
     int phase;
   };
   std::vector<PtChunk> pt_chunks;
+  // phases whose conversion is deferred to pt_upload_wait (one kernel per segment on the waiting stream instead of one per
+  // chunk behind its DMA): the segments, and the per-chunk formats the staging threads report through pinned memory
+  struct PtDeferred {
+    const uint32_t* d_stage;
+    uint32_t* d_dst;
+    uint32_t n;
+    size_t first_chunk;
+    int phase;
+  };
+  std::vector<PtDeferred> pt_deferred;
+  int pt_defer_mask = 0;
+  int pt_curve = 0;
+  PinnedBuf pt_fmt;
   std::atomic<int> pt_phase_count[2];
   hipError_t pt_err[Uploader::T] = {};
   bool pt_active = false;
@@ -779,7 +797,8 @@ int points_out(int curve, const uint32_t* d_in, uint32_t* d_out, size_t n) {
 // Segments carry a phase (0 or 1): the caller can start device work that needs only the phase-0 points while the
 // phase-1 points are still crossing PCIe (the prover's first round: L needs A_hi | B_lo, R the other halves).
 //   pt_upload_begin  starts the staging threads and returns; the caller's arrays are read until pt_upload_end returns
-//   pt_upload_wait   blocks until every chunk of `phase` has been enqueued, then orders stream `st` after them
+//   pt_upload_wait   blocks until every chunk of `phase` has been enqueued, then orders stream `st` after them (and, for a
+//                    phase of defer_mask, converts the phase's segments on `st`: one kernel a segment instead of one a chunk)
 //   pt_upload_end    joins the staging threads (every chunk enqueued; all phases) and reports their first error
 struct PtSeg {
   const uint64_t* src;
@@ -816,7 +835,7 @@ size_t stage_points(const uint64_t* src, uint32_t count, int fmt, void* buf, int
   return (size_t)count * 96;
 }
 
-int pt_upload_begin(int curve, const PtSeg* segs, int nseg, hipStream_t st) {
+int pt_upload_begin(int curve, const PtSeg* segs, int nseg, hipStream_t st, int defer_mask = 0) {
   Ctx& C = cx();
   Uploader& U = C.up;
   if (C.pt_active) return fail(BPGPU_E_STATE, "a point upload is already in flight on this context");
@@ -825,10 +844,15 @@ int pt_upload_begin(int curve, const PtSeg* segs, int nseg, hipStream_t st) {
   for (int g = 0; g < nseg; g++) total += segs[g].n;
   TRY(C.st_pts_in.ensure((total ? total : 1) * 96));
   C.pt_chunks.clear();
+  C.pt_deferred.clear();
+  C.pt_defer_mask = defer_mask;
+  C.pt_curve = curve;
   uint8_t* stage = (uint8_t*)C.st_pts_in.p;
   for (int ph = 0; ph < 2; ph++)
     for (int g = 0; g < nseg; g++) {
       if (segs[g].phase != ph) continue;
+      if (((defer_mask >> ph) & 1) && segs[g].n)
+        C.pt_deferred.push_back(Ctx::PtDeferred{(const uint32_t*)stage, segs[g].d_dst, (uint32_t)segs[g].n, C.pt_chunks.size(), ph});
       for (size_t o = 0; o < segs[g].n; o += PT_CHUNK) {
         const uint32_t cnt = (uint32_t)(segs[g].n - o < PT_CHUNK ? segs[g].n - o : PT_CHUNK);
         C.pt_chunks.push_back(Ctx::PtChunk{segs[g].src + o * (segs[g].fmt == 0 ? 12 : 8), cnt, segs[g].fmt, segs[g].d_dst + 16ull * o,
@@ -836,6 +860,7 @@ int pt_upload_begin(int curve, const PtSeg* segs, int nseg, hipStream_t st) {
         stage += (size_t)cnt * 96;
       }
     }
+  if (defer_mask) TRY(C.pt_fmt.ensure(C.pt_chunks.size() + 1));
   HIP_TRY(hipEventRecord(U.fence, st));  // the staging area and the destination are free once st gets here
   C.pt_phase_count[0].store(0);
   C.pt_phase_count[1].store(0);
@@ -847,10 +872,12 @@ int pt_upload_begin(int curve, const PtSeg* segs, int nseg, hipStream_t st) {
     Uploader& U = C.up;
     hipError_t r = hipSetDevice(device);
     if (r == hipSuccess) r = hipStreamWaitEvent(U.ws[w], U.fence, 0);
+    if (r == hipSuccess) r = hipStreamWaitEvent(U.cs[w], U.fence, 0);
     int cur = 0;
     auto close_phases = [&](int upto) {  // every phase below `upto` is complete for this worker (also after an error)
       while (cur < upto) {
-        if (r == hipSuccess) r = hipEventRecord(U.pdone[cur][w], U.ws[w]);
+        // (a deferred phase has no conversion kernels of its own: its last operation is a DMA)
+        if (r == hipSuccess) r = hipEventRecord(U.pdone[cur][w], ((C.pt_defer_mask >> cur) & 1) ? U.ws[w] : U.cs[w]);
         C.pt_phase_count[cur].fetch_add(1, std::memory_order_release);
         cur++;
       }
@@ -866,12 +893,26 @@ int pt_upload_begin(int curve, const PtSeg* segs, int nseg, hipStream_t st) {
       int cfmt = 0;
       const size_t bytes = curve == BPGPU_PALLAS ? stage_points<0>(ch.src, ch.count, ch.fmt, U.buf[w][slot], &cfmt)
                                                  : stage_points<1>(ch.src, ch.count, ch.fmt, U.buf[w][slot], &cfmt);
+      if ((C.pt_defer_mask >> ch.phase) & 1) ((volatile uint8_t*)C.pt_fmt.p)[k] = (uint8_t)cfmt;  // read by the segment's kernel
       if ((r = hipMemcpyAsync(ch.d_stage, U.buf[w][slot], bytes, hipMemcpyHostToDevice, U.ws[w])) != hipSuccess) continue;
       if ((r = hipEventRecord(U.ev[w][slot], U.ws[w])) != hipSuccess) continue;
-      if (curve == BPGPU_PALLAS)
-        k_points_in<0><<<cdiv(ch.count, 64), 64, 0, U.ws[w]>>>((const uint32_t*)ch.d_stage, ch.d_dst, ch.count, cfmt);
+      if ((C.pt_defer_mask >> ch.phase) & 1) continue;  // converted by pt_upload_wait, a segment at a time
+      // The conversion runs on a stream of its own, behind this chunk's DMA: a conversion kernel launched while a bucket
+      // accumulation holds the chip does not finish until that kernel ends (kernel trace of a 2^20-element proof: three
+      // 8 us conversions took 0.85 ms beside the first round's k_accum -- also as k_points_in_affine, 32 registers and
+      // raised priority), and on the DMA's stream it held the worker's later copies back with it.  Worth 0.1 ms of
+      // bpgpu_ipa_begin at 2^20 (tools/begin_ab.py, alternating sessions): the transfer itself is bound by the host side.
+      if ((r = hipStreamWaitEvent(U.cs[w], U.ev[w][slot], 0)) != hipSuccess) continue;
+      hipStream_t ks = U.cs[w];
+      if (cfmt == 1) {  // affine rows: the lean kernel that fits beside a running bucket accumulation
+        if (curve == BPGPU_PALLAS)
+          k_points_in_affine<0><<<cdiv(ch.count, 256), 256, 0, ks>>>((const uint32_t*)ch.d_stage, ch.d_dst, ch.count);
+        else
+          k_points_in_affine<1><<<cdiv(ch.count, 256), 256, 0, ks>>>((const uint32_t*)ch.d_stage, ch.d_dst, ch.count);
+      } else if (curve == BPGPU_PALLAS)
+        k_points_in<0><<<cdiv(ch.count, 64), 64, 0, ks>>>((const uint32_t*)ch.d_stage, ch.d_dst, ch.count, cfmt);
       else
-        k_points_in<1><<<cdiv(ch.count, 64), 64, 0, U.ws[w]>>>((const uint32_t*)ch.d_stage, ch.d_dst, ch.count, cfmt);
+        k_points_in<1><<<cdiv(ch.count, 64), 64, 0, ks>>>((const uint32_t*)ch.d_stage, ch.d_dst, ch.count, cfmt);
       r = hipGetLastError();
     }
     close_phases(2);
@@ -889,6 +930,18 @@ int pt_upload_wait(int phase, hipStream_t st) {
     if ((++looks & 255u) == 0) std::this_thread::yield(); else __builtin_ia32_pause();
   }
   for (int w = 0; w < U.nt; w++) HIP_TRY(hipStreamWaitEvent(st, U.pdone[phase][w], 0));
+  if ((C.pt_defer_mask >> phase) & 1) {  // the phase's DMAs are ordered before st now: convert its segments there
+    uint8_t* d_fmt = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&d_fmt, C.pt_fmt.p, 0));
+    for (const Ctx::PtDeferred& d : C.pt_deferred) {
+      if (d.phase != phase) continue;
+      if (C.pt_curve == BPGPU_PALLAS)
+        k_points_in_chunked<0><<<cdiv(d.n, 256), 256, 0, st>>>(d.d_stage, d.d_dst, d.n, PT_CHUNK, d_fmt + d.first_chunk);
+      else
+        k_points_in_chunked<1><<<cdiv(d.n, 256), 256, 0, st>>>(d.d_stage, d.d_dst, d.n, PT_CHUNK, d_fmt + d.first_chunk);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   return 0;
 }
 
@@ -1601,6 +1654,7 @@ void ctx_release(Ctx& C) {
   C.ipa_table.release();
   C.ipa_table_tmp.release();
   C.fold_alpha.release();
+  C.pt_fmt.release();
   C.ipa_pool_busy = false;
   C.h_winsum.release();
   C.up.release();
@@ -2617,7 +2671,9 @@ static int ipa_begin_common(int curve, const uint64_t* a_gens_xyz, const uint64_
                        {ip_gen_xyz, 1, 0, s->d_pts + 32 * np, 0},
                        {a_gens_xyz, h, 0, dA, 1},
                        {b_gens_xyz + 12 * h, n - h, 0, dB + 16 * h, 1}};
-      if ((rc = pt_upload_begin(curve, segs, 5, st)) != 0) break;
+      // (phase 1 crosses PCIe while L's k_accum holds the chip: no kernels of its own, or they and the DMAs queued behind
+      // them in the shared hardware queues wait for that kernel's end -- pt_upload_begin)
+      if ((rc = pt_upload_begin(curve, segs, 5, st, /* defer_mask = */ 2)) != 0) break;
       const uint32_t hn = (uint32_t)h, npu = (uint32_t)np;
       IpPair pl{0u, npu + hn}, pr{hn, npu};
       rc = ip_launch(curve, s->d_sc, s->d_sc, pl, pr, 2, hn, s->d_sc + 8ull * (2 * np), s->d_sc + 8ull * (2 * np + 1));

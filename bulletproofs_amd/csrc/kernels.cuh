@@ -839,15 +839,12 @@ __global__ void __launch_bounds__(256) k_reduce2(const uint32_t* __restrict__ pa
 // Format conversion kernels
 // ---------------------------------------------------------------------------
 // ark jacobian (96 B) or ark affine (64 B) -> dev affine (64 B)
+// one staged point (fmt 0: ark jacobian, 96 B; fmt 1: ark affine, 64 B) -> device affine
 template <int BF>
-__global__ void __launch_bounds__(256) k_points_in(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                   uint32_t n, int fmt) {
+__device__ __forceinline__ Aff point_in(const uint32_t* __restrict__ p, int fmt) {
   using F = Fp<BF>;
   using IO = PointIo<BF>;
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
   uint32_t wx[8], wy[8], wz[8];
-  const uint32_t* p = in + (uint64_t)i * (fmt == 0 ? 24 : 16);
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     wx[k] = p[k];
@@ -877,6 +874,50 @@ __global__ void __launch_bounds__(256) k_points_in(const uint32_t* __restrict__ 
     a.x = F::load_ark(wx);
     a.y = F::load_ark(wy);
   }
+  return a;
+}
+template <int BF>
+__global__ void __launch_bounds__(256) k_points_in(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                   uint32_t n, int fmt) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PointIo<BF>::store_dev_affine(out + 16ull * i, point_in<BF>(in + (uint64_t)i * (fmt == 0 ? 24 : 16), fmt));
+}
+
+// A whole segment of a chunked upload at once (bpgpu.hip, pt_upload_begin with a deferred phase): the staging area
+// holds the segment's chunks `chunk` points apart at 96 B a point, each chunk in the format its staging thread found
+// (fmt[c], written to pinned host memory before the chunk's DMA was enqueued): rows of 64 B or of 96 B from the
+// chunk's start.
+template <int BF>
+__global__ void __launch_bounds__(256) k_points_in_chunked(const uint32_t* __restrict__ stage, uint32_t* __restrict__ out,
+                                                           uint32_t n, uint32_t chunk, const uint8_t* __restrict__ fmt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = i / chunk, r = i - c * chunk;
+  const int f = fmt[c];  // uniform over a workgroup when 256 divides `chunk`
+  PointIo<BF>::store_dev_affine(out + 16ull * i, point_in<BF>(stage + 24ull * c * chunk + (uint64_t)r * (f == 0 ? 24 : 16), f));
+}
+
+// The same conversion for rows the host has already found affine (x, y in ark form, 64 B): no inversion path, 32
+// registers, whole 256-thread workgroups -- what the pipelined uploads launch per chunk.  (Shaped to fit beside a bucket
+// accumulation -- few registers, no LDS, raised wave priority -- it still does not finish before that kernel ends:
+// kernel trace of a 2^20-element proof; the uploader therefore keeps conversions off the DMA streams, bpgpu.hip.)
+template <int BF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_points_in_affine(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+  using F = Fp<BF>;
+  using IO = PointIo<BF>;
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* p = reinterpret_cast<const uint4*>(in + 16ull * i);
+  const uint4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+  const uint32_t wx[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  const uint32_t wy[8] = {r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+  Aff a;
+  a.inf = IO::all_zero(wx) && IO::all_zero(wy);
+  a.x = F::load_ark(wx);
+  a.y = F::load_ark(wy);
   IO::store_dev_affine(out + 16ull * i, a);
 }
 
