@@ -453,6 +453,35 @@ void write_xy_inf(const host::HPoint<BF>& p, uint64_t out[9]) {
   out[8] = finite ? 0 : 1;
 }
 
+// The same for the M results of a batch with ONE field inversion (Montgomery's trick): a host inversion is a Fermat ladder
+// of ~320 multiplications (8 us), as much as the rest of a short round's tail, and a k-ary round normalises up to 32 points.
+template <int BF>
+void write_xy_inf_batch(const host::HPoint<BF>* p, int M, uint64_t (*out)[9]) {
+  using F = host::HF<BF>;
+  host::H4 z[MSM_MAX_BATCH], pre[MSM_MAX_BATCH];
+  host::H4 run = F::one();
+  for (int m = 0; m < M; m++) {
+    const bool finite = !p[m].inf && !F::is_zero(p[m].zz);
+    z[m] = finite ? F::mul(p[m].zz, p[m].zzz) : F::one();
+    pre[m] = run;
+    run = F::mul(run, z[m]);
+  }
+  host::H4 inv = F::inv(run);
+  for (int m = M - 1; m >= 0; m--) {
+    const host::H4 zi = F::mul(inv, pre[m]);  // 1 / (zz zzz) of result m
+    inv = F::mul(inv, z[m]);
+    const bool finite = !p[m].inf && !F::is_zero(p[m].zz);
+    host::H4 x = F::zero(), y = F::zero();
+    if (finite) {
+      x = F::mul(p[m].x, F::mul(zi, p[m].zzz));
+      y = F::mul(p[m].y, F::mul(zi, p[m].zz));
+    }
+    memcpy(out[m], x.v, 32);
+    memcpy(out[m] + 4, y.v, 32);
+    out[m][8] = finite ? 0 : 1;
+  }
+}
+
 // Horner combine (msm.rs:177-190), high bit position to low with one doubling per position.
 // Window w contributes its component P at position c w and U_i at position c w + s + i
 // (kernels.cuh, bucket reduction); comps = 2 + nbits points per window (P comes in two halves), ark-form XYZZ words.
@@ -738,11 +767,11 @@ int msm_core(const uint32_t* d_points, const uint32_t* d_scalars, MsmPlan plan, 
     task(0);
     C.hpool.wait();
   }
-  for (int m = 0; m < plan.M; m++) {
-    host::HPoint<BF> total = part[m * G];
-    for (int g = 1; g < G; g++) total = host::HEc<BF>::add(total, part[m * G + g]);
-    write_xy_inf<BF>(total, out[m]);
-  }
+  for (int m = 0; m < plan.M; m++)  // (part[m G] is dead after this: the totals are gathered at the front)
+    for (int g = 1; g < G; g++) part[m * G] = host::HEc<BF>::add(part[m * G], part[m * G + g]);
+  if (G > 1)
+    for (int m = 1; m < plan.M; m++) part[m] = part[m * G];
+  write_xy_inf_batch<BF>(part, plan.M, out);
   auto t1 = std::chrono::steady_clock::now();
   C.msm_ms[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
   C.msm_timed = phase_events;  // the GPU phases are read off the events when bpgpu_last_msm_timings asks
