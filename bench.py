@@ -465,7 +465,7 @@ def next_rows_leg(ffi, curve, mad_peak):
                                 "note": "frac prices the REFERENCE's double-and-add (255 doublings + 127.5 additions, 7 / 11 field muls x 136 "
                                         "mads) against the kernel's time; the kernel itself runs a GLV-split, signed 3-bit windowed chain "
                                         "(132 Jacobian doublings + about 78 mixed additions): frac_executed"}
-    # k-ary generator fold (ipa_to_bp_unroll.rs:253-260): ck = 2^16, k = 8, y = powers(x, 0..8) -> Horner: 7 monic folds
+    # k-ary generator fold (ipa_to_bp_unroll.rs:253-260): ck = 2^16, k = 8, y = powers(x, 0..8) -> one launch of k_fold_multi
     ck, k = 1 << 16, 8
     x = synth_scalars(1, 31)[0]
     y = ffi.powers(curve, x, 0, k)

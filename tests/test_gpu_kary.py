@@ -77,7 +77,7 @@ def test_fold_scalars_kary(ffi, c):
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
 def test_fold_points_kary_small(ffi, c):
-    """Against the big-integer model: powers (Horner path), arbitrary multipliers (general path),
+    """Against the big-integer model: powers (chunk 0 added as it is), arbitrary multipliers, k = 2 (k_fold_monic),
     identity points from zero padding, repeated points (doubling inside the fold)."""
     cid = c.curve_id
     x = H.rand_scalars(c, 1, 940)[0]
