@@ -226,12 +226,19 @@ def test_ipa_prove_large_unpadded_with_mixed_z(bp):
     x, y = H.jac_from_abi(c, A[70_000:70_001])[0]
     A[70_000] = H.jac_abi(c, [(x * 25 % c.q, y * 125 % c.q, 5)])[0]   # same point, Z = 5
     A[40_000] = ident[0]                                               # an identity among the generators
+    # (A[40 000] and B[90 000] belong to the upload's second phase, whose chunks are converted a segment at a time by
+    # k_points_in_chunked from per-chunk formats; A[70 000] to the first, converted chunk by chunk)
+    B = B.copy()
+    xb, yb = H.jac_from_abi(c, B[90_000:90_001])[0]
+    B[90_000] = H.jac_abi(c, [(xb * 9 % c.q, yb * 27 % c.q, 3)])[0]    # same point, Z = 3
     np_ = 1 << 17
     An = A.copy()
     An[70_000] = H.jac_abi(c, [(x, y)])[0]
+    Bn = B.copy()
+    Bn[90_000] = H.jac_abi(c, [(xb, yb)])[0]
     pad_p = np.tile(ident, (np_ - n, 1))
     zs = np.zeros((np_ - n, 4), np.uint64)
-    ls, rs, ch, fa, fb = co.bp_prove(cid, np.concatenate([An, pad_p]), np.concatenate([B, pad_p]), q,
+    ls, rs, ch, fa, fb = co.bp_prove(cid, np.concatenate([An, pad_p]), np.concatenate([Bn, pad_p]), q,
                                      np.concatenate([a, zs]), np.concatenate([b, zs]), seed, threads=16)
     pf = bp.bp_prove(cid, A, B, q, a, b, seed)
     assert (pf["ls"] == ls).all() and (pf["rs"] == rs).all() and (pf["challenges"] == ch).all()
