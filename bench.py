@@ -495,6 +495,39 @@ def next_rows_leg(ffi, curve, mad_peak):
                                        "multiplications per output against the same time"}
     d_g.free()
     d_o.free()
+    # one whole k-ary round (bp_rec_kary.rs:27-143) from host vectors at n = 2^17, k = 8: the 2 (k - 1) cross-term MSMs as
+    # one batch, the two scalar folds and the two generator folds -- as the five C-ABI calls, and as the host mirror's
+    # prove_step (which, like the reference, also clones and pads its vectors and runs the transcript)
+    nk = 1 << 17
+    A, B, q = pts[:nk], pts[nk:2 * nk], synth_points(ffi, curve, 3, seed=41)[2:]
+    a, b = sc[:nk], sc[nk:2 * nk]
+    yi = ffi.powers(curve, ark_bp.scalar_inverse(curve, x), 0, k)
+
+    def abi_calls():
+        ffi.kary_cross_terms(curve, A, B, q, a, b, k)
+        ffi.fold_scalars_kary(curve, a, k, y)
+        ffi.fold_scalars_kary(curve, b, k, yi)
+        ffi.fold_points_kary(curve, A, k, yi)
+        ffi.fold_points_kary(curve, B, k, y)
+    res = ark_bp.commit(curve, A, B, q, a, b)
+    seed = b"bench k-ary round".ljust(32, b"\0")
+    best_abi = best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        abi_calls()
+        best_abi = min(best_abi, time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        step = ark_bp.kary_prove_step(curve, k, A, B, q, res, a, b, seed)
+        best = min(best, time.perf_counter() - t0)
+    v = ark_bp.kary_verify_step(curve, k, A, B, q, res, step["pos_cross"], step["neg_cross"], seed)
+    agree = bool((v["a_gens"] == step["a_gens"]).all() and (v["b_gens"] == step["b_gens"]).all() and (v["result"] == step["result"]).all())
+    out["kary_round"] = {"n": nk, "k": k, "abi_calls_ms": best_abi * 1e3, "host_mirror_prove_step_ms": best * 1e3,
+                         "cross_term_msms": 2 * (k - 1),
+                         "note": "host vectors in, folded vectors out (PCIe both ways included).  abi_calls_ms: bpgpu_kary_cross_terms + "
+                                 "bpgpu_fold_scalars_kary x 2 + bpgpu_fold_points_kary x 2 on the caller's arrays; "
+                                 "host_mirror_prove_step_ms: KaryBp::prove_step of the C++ mirror, which clones, pads and concatenates "
+                                 "its vectors the way the reference does (fresh allocations, first-touch page faults) and hashes the transcript",
+                         "verifier_step_reaches_the_same_instance": agree}
     # k-ary scalar fold (ipa_to_bp_unroll.rs:248-252): ck = 2^20, k = 8: 32 (k + 1) B per output
     ck = 1 << 20
     d_v = ffi.scalars_to_device(synth_scalars(ck * k, 32))
