@@ -1302,36 +1302,45 @@ int fold_multi(int curve, const uint32_t* p, const uint32_t* q, const uint64_t* 
   MultiOps ops;
   memset(&ops, 0, sizeof ops);
   ops.m = (uint32_t)m;
-  uint32_t nops = 0, pending = 0, adds = 0;
-  bool fits = true;
-  auto emit = [&](uint32_t v) {
-    if (nops < (uint32_t)MULTI_MAX_OPS) ops.op[nops++] = (uint16_t)v; else fits = false;
-  };
+  // short vectors: 2 or 4 lanes an output while that still leaves about a wave a SIMD (k_fold_multi); each lane gets
+  // every doubling and its turn of the additions
+  const uint64_t chip_lanes = (uint64_t)C.num_cus * 256;
+  const uint32_t lanes = (uint64_t)n * 4 <= chip_lanes ? 4u : ((uint64_t)n * 2 <= chip_lanes ? 2u : 1u);
+  ops.lanes = lanes;
+  std::vector<uint16_t> list[4];
+  uint32_t pending[4] = {0, 0, 0, 0}, adds = 0;
   for (int pos = len - 1; pos >= 0; pos--) {
-    pending++;
+    for (uint32_t r = 0; r < lanes; r++) pending[r]++;
     for (int t = 0; t < m; t++) {
       if (pos >= plan[t].len) continue;
       const uint32_t code = (plan[t].codes[pos >> 3] >> ((pos & 7) * 4)) & 15u;
       if (!(code & 3u)) continue;
-      for (; pending > 31; pending -= 31) emit(31u << 7);
-      emit(0x1000u | (pending << 7) | ((uint32_t)t << 4) | code);
-      pending = 0;
+      const uint32_t r = adds % lanes;
+      for (; pending[r] > 31; pending[r] -= 31) list[r].push_back((uint16_t)(31u << 7));
+      list[r].push_back((uint16_t)(0x1000u | (pending[r] << 7) | ((uint32_t)t << 4) | code));
+      pending[r] = 0;
       adds++;
     }
   }
-  for (; pending; pending -= (pending > 31 ? 31 : pending)) emit((pending > 31 ? 31u : pending) << 7);
-  if (!fits) return 1;
-  ops.nops = nops;
+  uint32_t nops = 0;
+  for (uint32_t r = 0; r < lanes; r++) {
+    for (; pending[r]; pending[r] -= (pending[r] > 31 ? 31 : pending[r])) list[r].push_back((uint16_t)((pending[r] > 31 ? 31u : pending[r]) << 7));
+    ops.start[r] = nops;
+    if (nops + list[r].size() > (size_t)MULTI_MAX_OPS) return 1;
+    memcpy(ops.op + nops, list[r].data(), list[r].size() * sizeof(uint16_t));
+    nops += (uint32_t)list[r].size();
+  }
+  for (uint32_t r = lanes; r <= 4; r++) ops.start[r] = nops;
   TRY(C.fold_alpha.ensure((size_t)m * n * 64));
   C.fold_ops[0] += n;
-  C.fold_ops[1] += (uint64_t)n * (uint64_t)len;
-  C.fold_ops[2] += (uint64_t)n * (adds + (p ? 1u : 0u));
+  C.fold_ops[1] += (uint64_t)n * (uint64_t)len * lanes;                     // every lane of an output doubles through all positions
+  C.fold_ops[2] += (uint64_t)n * (adds + (p ? 1u : 0u) + (lanes - 1));    // and lanes - 1 additions join the partial sums
   C.fold_ops[3] = 3;
   OpSpan span(C);
   if (curve == BPGPU_PALLAS)
-    k_fold_multi<0><<<cdiv(n, 256), 256, 0, C.stream>>>(q, p, C.fold_alpha.as<uint32_t>(), o, ops, n);
+    k_fold_multi<0><<<cdiv(n, 256 / lanes), 256, 0, C.stream>>>(q, p, C.fold_alpha.as<uint32_t>(), o, ops, n);
   else
-    k_fold_multi<1><<<cdiv(n, 256), 256, 0, C.stream>>>(q, p, C.fold_alpha.as<uint32_t>(), o, ops, n);
+    k_fold_multi<1><<<cdiv(n, 256 / lanes), 256, 0, C.stream>>>(q, p, C.fold_alpha.as<uint32_t>(), o, ops, n);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -1546,10 +1546,15 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
 // ---------------------------------------------------------------------------
 constexpr int MULTI_MAX_M = 7;
 constexpr int MULTI_MAX_OPS = 768;
-// op: bits 0-3 digit code (as in MonicPlan), 4-6 generator t, 7-11 doublings before the addition, 12 an addition follows
+// op: bits 0-3 digit code (as in MonicPlan), 4-6 generator t, 7-11 doublings before the addition, 12 an addition follows.
+// Short vectors (fewer outputs than the chip has lanes at a wave per SIMD): `lanes` = 2 or 4 lanes share an output, each
+// with its own operation list op[start[r] .. start[r + 1]) -- every list doubles through all positions, the additions
+// are dealt out in turn -- and the partial sums meet in LDS (as in k_fold_joint4_split).  The time of such a launch is its
+// longest chain: 128 doublings + 381 / lanes additions.
 struct MultiOps {
   uint16_t op[MULTI_MAX_OPS];
-  uint32_t nops;
+  uint32_t start[5];
+  uint32_t lanes;  // 1, 2 or 4
   uint32_t m;
 };
 template <int BF>
@@ -1559,19 +1564,23 @@ __global__ void __launch_bounds__(256) k_fold_multi(const uint32_t* __restrict__
   using E = Ec<BF>;
   using IO = PointIo<BF>;
   __shared__ uint32_t tree[512][9];
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int32_t xch[3 * 37 * 64];  // XYZZ partial sums of roles 1 .. lanes-1 (36 limbs + identity flag per output)
+  const uint32_t lanes = ops.lanes, per_wg = 256u / lanes;          // wave-uniform
+  const uint32_t col = threadIdx.x % per_wg, role = threadIdx.x / per_wg;  // a wave has one role
+  const uint32_t i = blockIdx.x * per_wg + col;
   const bool active = i < n;
-  const int m = (int)ops.m;  // wave-uniform
+  const int m = (int)ops.m;
   const Fe zeta = F::from_const(CurveConsts<BF>::ZETA261);
   const Fe zeta2 = F::sqr(zeta);
   {
-    // Q'_t = Q_t - phi(Q_t) for every generator of the lane: prefix products of the slopes' denominators, one inversion
+    // Q'_t = Q_t - phi(Q_t) for the generators t = role (mod lanes) of the lane's output: prefix products of the slopes'
+    // denominators, one inversion
     Fe pre[MULTI_MAX_M];
     Fe run = F::one();
 #pragma unroll
     for (int t = 0; t < MULTI_MAX_M; t++) {
       pre[t] = run;
-      if (t < m && active) {
+      if (t < m && active && (uint32_t)t % lanes == role) {
         const Aff Q = IO::load_dev_affine(q + 16ull * ((uint64_t)t * n + i));
         if (!Q.inf) run = F::mul(run, alpha_den<BF>(Q, zeta));
       }
@@ -1579,7 +1588,7 @@ __global__ void __launch_bounds__(256) k_fold_multi(const uint32_t* __restrict__
     Fe inv = block_inverse_256<BF>(run, tree);
 #pragma unroll
     for (int t = MULTI_MAX_M - 1; t >= 0; t--) {
-      if (t < m && active) {
+      if (t < m && active && (uint32_t)t % lanes == role) {
         const Aff Q = IO::load_dev_affine(q + 16ull * ((uint64_t)t * n + i));
         Aff A;
         A.inf = true;
@@ -1589,21 +1598,26 @@ __global__ void __launch_bounds__(256) k_fold_multi(const uint32_t* __restrict__
           inv = F::mul(inv, alpha_den<BF>(Q, zeta));
           A = alpha_point<BF>(Q, it, zeta2);
         }
-        IO::store_dev_affine(alpha + 16ull * ((uint64_t)t * n + i), A);  // read back by this lane only
+        IO::store_dev_affine(alpha + 16ull * ((uint64_t)t * n + i), A);  // read back by the lanes of this output only
       }
+    }
+    if (lanes > 1) {  // the other roles of the output (same workgroup) read these rows
+      __threadfence();
+      __syncthreads();
     }
   }
   Jac acc = E::jidentity();
-  if (active && ops.nops) {
+  const uint32_t j0 = ops.start[role], j1 = ops.start[role + 1];
+  if (active && j0 < j1) {
     auto operand = [&](uint32_t op) -> const uint4* {
       const uint32_t t = (op >> 4) & 7u;
       return reinterpret_cast<const uint4*>(((op & 4u) ? alpha : q) + 16ull * ((uint64_t)t * n + i));
     };
-    const uint4* pp = operand(ops.op[0]);
+    const uint4* pp = operand(ops.op[j0]);
     uint4 r0 = pp[0], r1 = pp[1], r2 = pp[2], r3 = pp[3];
-    for (uint32_t j = 0; j < ops.nops; j++) {
+    for (uint32_t j = j0; j < j1; j++) {
       const uint32_t op = ops.op[j];  // wave-uniform
-      pp = operand(ops.op[j + 1 < ops.nops ? j + 1 : j]);
+      pp = operand(ops.op[j + 1 < j1 ? j + 1 : j]);
       const uint4 n0 = pp[0], n1 = pp[1], n2 = pp[2], n3 = pp[3];
       for (uint32_t d = (op >> 7) & 31u; d > 0; d--) acc = E::jdbl(acc);
       if (op & 0x1000u) {
@@ -1620,10 +1634,62 @@ __global__ void __launch_bounds__(256) k_fold_multi(const uint32_t* __restrict__
       r3 = n3;
     }
   }
-  if (active && p) E::jmadd(acc, IO::load_dev_affine(p + 16ull * i));
-  const bool fin = active && !acc.inf;
-  const Fe inv = block_inverse_256<BF>(fin ? acc.z : F::one(), tree);
-  if (active) IO::store_dev_affine(o + 16ull * i, E::jto_affine_with(acc, inv));
+  if (active && p && role == 0) E::jmadd(acc, IO::load_dev_affine(p + 16ull * i));
+  if (lanes == 1) {  // one lane an output: straight to affine through the shared inversion of Z
+    const bool fin = active && !acc.inf;
+    const Fe inv = block_inverse_256<BF>(fin ? acc.z : F::one(), tree);
+    if (active) IO::store_dev_affine(o + 16ull * i, E::jto_affine_with(acc, inv));
+    return;
+  }
+  // several lanes an output: the partial sums meet in LDS as XYZZ (Ec::add is the tested general addition)
+  Xyzz r = E::identity();
+  if (active && !acc.inf) {
+    r.x = acc.x;
+    r.y = acc.y;
+    r.zz = F::sqr(acc.z);
+    r.zzz = F::mul(r.zz, acc.z);
+    r.inf = false;
+  }
+  if (role != 0) {
+    int32_t* x = xch + (size_t)(role - 1) * 37 * per_wg;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      x[k * per_wg + col] = r.x.l[k];
+      x[(9 + k) * per_wg + col] = r.y.l[k];
+      x[(18 + k) * per_wg + col] = r.zz.l[k];
+      x[(27 + k) * per_wg + col] = r.zzz.l[k];
+    }
+    x[36 * per_wg + col] = r.inf ? 1 : 0;
+  }
+  __syncthreads();
+  if (role == 0) {
+    for (uint32_t rr = 1; rr < lanes; rr++) {
+      const int32_t* x = xch + (size_t)(rr - 1) * 37 * per_wg;
+      Xyzz b;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        b.x.l[k] = x[k * per_wg + col];
+        b.y.l[k] = x[(9 + k) * per_wg + col];
+        b.zz.l[k] = x[(18 + k) * per_wg + col];
+        b.zzz.l[k] = x[(27 + k) * per_wg + col];
+      }
+      b.inf = x[36 * per_wg + col] != 0;
+      r = E::add(r, b);
+    }
+  }
+  const bool fin = role == 0 && active && !r.inf;
+  const Fe inv = block_inverse_256<BF>(fin ? F::mul(r.zz, r.zzz) : F::one(), tree);
+  if (role == 0 && active) {
+    Aff a;
+    a.inf = !fin;
+    a.x = F::zero();
+    a.y = F::zero();
+    if (fin) {
+      a.x = F::mul(r.x, F::mul(inv, r.zzz));
+      a.y = F::mul(r.y, F::mul(inv, r.zz));
+    }
+    IO::store_dev_affine(o + 16ull * i, a);
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -155,6 +155,21 @@ def test_fold_points_kary_and_hadamard_gp_vs_c_oracle(ffi, c):
     assert (ffi.hadamard_points(cid, gp, es) == co.hadamard_points(cid, gp, es)).all()
 
 
+@pytest.mark.parametrize("k,ck", [(4, 40_000), (3, 20_000), (8, 9_000)], ids=["one-lane", "two-lanes", "four-lanes"])
+def test_fold_points_kary_lane_splits_vs_c_oracle(ffi, k, ck):
+    """The shared-chain fold gives short vectors 2 or 4 lanes an output (ck <= 2^15 / 2^14 on a 256-CU chip) and long
+    ones a lane each: one size per schedule against Oracle B, with an identity generator and a repeated one."""
+    from bulletproofs_amd import ark_bp
+    cid = 0
+    pts, sc = ark_bp.msm_bench_inputs(cid, k * ck)
+    g = pts.copy()
+    g[ck + 7] = co.normalise(cid, np.zeros((1, 12), np.uint64))[0]
+    g[2 * ck + 11] = g[11]
+    for y in (co.powers(cid, sc[0], 0, k), sc[3:3 + k]):
+        want = co.fold_points_kary(cid, g, k, y, threads=16)
+        assert (ffi.fold_points_kary(cid, g, k, y) == want).all()
+
+
 def _cross_terms_by_the_reference_recipe(c, cid, A, B, q, a, b, k):
     """pos / neg exactly as ipa_to_bp_unroll.rs:189-215 writes them: k (k - 1) separate MSMs X[i, j] (Oracle B), summed
     (big-integer model's affine addition)."""
