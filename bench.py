@@ -476,7 +476,7 @@ def next_rows_leg(ffi, curve, mad_peak):
         ffi.fold_points_kary_device(curve, d_g, ck, k, y, d_o)
         best = min(best, ffi.last_op_ms())
     outputs, dbls, adds, kind = ffi.last_fold_ops()  # group operations of the whole call
-    assert kind == 3, "unexpected fold kernel"
+    assert kind == 4, "unexpected fold kernel"
     yard = (dbls * MULS_PER_DOUBLE + adds * MULS_PER_MIXED_ADD) * MADS_PER_FIELD_MUL
     execd = dbls * EXEC_MADS_JAC_DOUBLE + adds * EXEC_MADS_JAC_MIXED_ADD
     # the reference's schedule for the same outputs: k - 1 scalar multiplications by double-and-add (mul of a 255-bit

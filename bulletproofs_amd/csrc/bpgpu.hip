@@ -1120,11 +1120,32 @@ int make_fold_plan(const uint64_t s_lo_ark[4], const uint64_t s_hi_ark[4], FoldP
   return 0;
 }
 
+int fold_multi(int curve, const uint32_t* p, const uint32_t* q, const uint64_t* s, int m, uint32_t n, uint32_t* o);
+
 int fold_points_launch(int curve, const uint32_t* g0, uint32_t* o0, const uint64_t lo0[4], const uint64_t hi0[4],
                        const uint32_t* g1, uint32_t* o1, const uint64_t lo1[4], const uint64_t hi1[4], int nvec,
                        uint32_t n) {
   if (n == 0) return 0;
   Ctx& C = cx();
+  // Both multipliers on one doubling chain with Eisenstein width-2 digits (k_fold_multi: 128 doublings + ~110 additions
+  // an output, 2 or 4 lanes an output for short vectors) -- 7.5 -> 6.5 ms at 2^19 outputs, 1.04 -> 0.70 ms at 2^14 against
+  // k_fold_points below (GLV halves in joint sparse form: ~130 additions), which stays as the path for a schedule that does
+  // not fit that kernel's operation list.  In place (o == g) is fine there: a lane reads its own column only, before the
+  // output's one store.
+  {
+    OpSpan span(C);
+    C.fold_ops[0] = C.fold_ops[1] = C.fold_ops[2] = 0;
+    uint64_t s2[8];
+    memcpy(s2, lo0, 32);
+    memcpy(s2 + 4, hi0, 32);
+    int rc = fold_multi(curve, nullptr, g0, s2, 2, n, o0);
+    if (rc == 0 && nvec > 1) {
+      memcpy(s2, lo1, 32);
+      memcpy(s2 + 4, hi1, 32);
+      rc = fold_multi(curve, nullptr, g1, s2, 2, n, o1);
+    }
+    if (rc <= 0) return rc;
+  }
   Plans2<FoldPlan> plans;  // kernel arguments
   if (curve == BPGPU_PALLAS) {
     TRY(make_fold_plan<0>(lo0, hi0, plans.p[0]));
@@ -1335,7 +1356,7 @@ int fold_multi(int curve, const uint32_t* p, const uint32_t* q, const uint64_t* 
   C.fold_ops[0] += n;
   C.fold_ops[1] += (uint64_t)n * (uint64_t)len * lanes;                     // every lane of an output doubles through all positions
   C.fold_ops[2] += (uint64_t)n * (adds + (p ? 1u : 0u) + (lanes - 1));    // and lanes - 1 additions join the partial sums
-  C.fold_ops[3] = 3;
+  C.fold_ops[3] = 4;
   OpSpan span(C);
   if (curve == BPGPU_PALLAS)
     k_fold_multi<0><<<cdiv(n, 256 / lanes), 256, 0, C.stream>>>(q, p, C.fold_alpha.as<uint32_t>(), o, ops, n);

@@ -1542,7 +1542,8 @@ __global__ void __launch_bounds__(256) k_fold_monic(const uint32_t* p0, const ui
 // inversion for all of a lane's generators) to `alpha`, then walks a host-made list of operations -- "d doublings,
 // then add the point of digit code c of generator t" -- and loads the operand of the NEXT operation while the
 // current one runs (a lane reads only its own column: coalesced 64-byte rows; 2 ms of arithmetic hide the latency).
-// o may alias p; o and alpha must not overlap q.
+// o may alias p, and q as well (the two-multiplier fold in place): a lane reads its own column only and the output's
+// one store comes after every read of it; alpha must not overlap either.
 // ---------------------------------------------------------------------------
 constexpr int MULTI_MAX_M = 7;
 constexpr int MULTI_MAX_OPS = 768;
@@ -1558,7 +1559,7 @@ struct MultiOps {
   uint32_t m;
 };
 template <int BF>
-__global__ void __launch_bounds__(256) k_fold_multi(const uint32_t* __restrict__ q, const uint32_t* p, uint32_t* __restrict__ alpha,
+__global__ void __launch_bounds__(256) k_fold_multi(const uint32_t* q, const uint32_t* p, uint32_t* __restrict__ alpha,
                                                     uint32_t* o, const MultiOps ops, uint32_t n) {
   using F = Fp<BF>;
   using E = Ec<BF>;

@@ -311,7 +311,8 @@ int bpgpu_last_msm_entries(uint64_t* entries);
 int bpgpu_last_op_ms(float* ms);
 /* Group operations of the last generator-fold launch on the primary context, summed over its lanes:
  * [0] outputs, [1] doublings, [2] mixed additions (non-zero digits of the recoded shared multipliers, plus
- * the final P + ...), [3] kernel (1 k_fold_monic, 2 k_fold_joint4, 3 k_fold_points): what bench.py prices
+ * the final P + ...), [3] kernel (1 k_fold_monic, 2 k_fold_joint4, 3 k_fold_points, 4 k_fold_multi: then summed over the launches
+ * of the call): what bench.py prices
  * the fold kernels with. */
 int bpgpu_last_fold_ops(uint64_t out[4]);
 /* Sustained v_mad_u64_u32 issue rate (lane-ops/s) measured by a register-only loop:
