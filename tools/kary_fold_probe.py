@@ -14,7 +14,7 @@ ffi.init(0)
 curve = 0
 base = bench.synth_points(ffi, curve, 1 << 16, seed=3)
 x = bench.synth_scalars(1, 31)[0]
-for ck, k in [(1 << 14, 8), (1 << 15, 8), (1 << 16, 8), (1 << 16, 4), (1 << 16, 3), (1 << 16, 16), (1 << 12, 8), (1 << 18, 8), (1 << 20, 8), (1 << 20, 3)]:
+for ck, k in [(1 << 18, 4), (1 << 19, 4), (1 << 18, 2), (1 << 14, 8), (1 << 15, 8), (1 << 16, 8), (1 << 16, 4), (1 << 16, 3), (1 << 16, 16), (1 << 12, 8), (1 << 18, 8), (1 << 20, 8), (1 << 20, 3)]:
     y = ffi.powers(curve, x, 0, k)
     reps = -(-ck * k // len(base))
     d_g = ffi.points_to_device(curve, np.concatenate([base] * reps)[:ck * k])
