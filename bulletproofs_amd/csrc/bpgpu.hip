@@ -2215,10 +2215,12 @@ int fold_points_kary_launch(int curve, const uint32_t* d_g, size_t ck, size_t k,
   auto chunk = [&](size_t j) { return d_g + 16ull * j * ck; };
   // Two multipliers or more: groups of up to seven ride one doubling chain each (k_fold_multi); chunk 0 is the first
   // group's addend when y[0] = 1 (the reference always passes powers(x, 0..k)), the output so far the later groups'.
-  if (k >= 3) {
-    host::H4 y0;
-    memcpy(y0.v, y, 32);
-    const bool monic = curve == BPGPU_PALLAS ? host::HF<1>::eq(y0, host::HF<1>::one()) : host::HF<0>::eq(y0, host::HF<0>::one());
+  host::H4 y0;
+  memcpy(y0.v, y, 32);
+  const bool monic = curve == BPGPU_PALLAS ? host::HF<1>::eq(y0, host::HF<1>::one()) : host::HF<0>::eq(y0, host::HF<0>::one());
+  // (two chunks with y[0] = 1 are one k_fold_monic launch, operands in registers; with y[0] != 1 they are two of them, or
+  // one shared chain here)
+  if (k >= 3 || (k == 2 && !monic)) {
     C.fold_ops[0] = C.fold_ops[1] = C.fold_ops[2] = 0;
     size_t j = monic ? 1 : 0;
     const uint32_t* addend = monic ? chunk(0) : nullptr;
