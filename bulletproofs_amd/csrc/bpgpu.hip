@@ -2051,6 +2051,13 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
                       const uint64_t final_b[4], uint64_t out_xy_inf[9]) {
   Ctx& C = cx();
   const bool from_device = d_q != nullptr;
+  bool piped = false;  // a chunked generator upload is in flight
+  struct PipeGuard {   // the caller's arrays are read until pt_upload_end returns: on every path out of here
+    bool& on;
+    ~PipeGuard() {
+      if (on) (void)pt_upload_end();
+    }
+  } pipe_guard{piped};
   if (k > 30) return fail(BPGPU_E_ARG, "too many rounds");
   const size_t np = (size_t)1 << k;
   if (pow2_at_least(n < 1 ? 1 : n) != np) return fail(BPGPU_E_ARG, "proof has %zu rounds but the generators need %zu elements", k, n);
@@ -2090,10 +2097,10 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
         // the staging area is st_pts_in: the proof's few points below go behind the generators' 2 n slots
         TRY(C.st_pts_in.ensure((2 * n + 1 + 2 * k) * 96));
         stg = (uint8_t*)C.st_pts_in.p;
+        // the chunks cross PCIe on the staging threads' streams while this stream expands the scalars and sorts them:
+        // the MSM's accumulation is what waits for the last chunk (points_ready below)
         TRY(pt_upload_begin(curve, segs, 2, st));
-        const int rc_w = pt_upload_wait(0, st), rc_e = pt_upload_end();
-        TRY(rc_w);
-        TRY(rc_e);
+        piped = true;
       } else {
         HIP_TRY(upload_async(stg, a_gens_xyz, n * 96, st));
         HIP_TRY(upload_async(stg + n * 96, b_gens_xyz, n * 96, st));
@@ -2125,7 +2132,12 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
   else
     k_verify_scalars<0><<<dim3(gx, 2), 256, 0, st>>>(C.st_ip.as<uint32_t>(), ds, (uint32_t)np, (int)k);
   HIP_TRY(hipGetLastError());
-  return msm_dispatch(curve, dp, ds, single_plan((uint32_t)total), (uint64_t(*)[9])out_xy_inf);
+  if (!piped) return msm_dispatch(curve, dp, ds, single_plan((uint32_t)total), (uint64_t(*)[9])out_xy_inf);
+  const std::function<int()> ready = [&]() -> int { return pt_upload_wait(0, st); };
+  const int rc = msm_dispatch(curve, dp, ds, single_plan((uint32_t)total), (uint64_t(*)[9])out_xy_inf, &ready);
+  piped = false;
+  const int rc_up = pt_upload_end();
+  return rc ? rc : rc_up;
 }
 }  // namespace
 }  // extern "C++"
