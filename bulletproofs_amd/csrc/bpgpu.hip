@@ -984,6 +984,15 @@ int pt_upload_end() {
   return 0;
 }
 
+// While `on` is set a chunked upload is in flight: the caller's arrays are read until pt_upload_end returns, on every
+// path out of the scope.
+struct PipeGuard {
+  bool& on;
+  ~PipeGuard() {
+    if (on) (void)pt_upload_end();
+  }
+};
+
 // the whole thing for one array on the context's stream: d_out is valid for work enqueued on st after the call
 int upload_points(int curve, const uint64_t* points, size_t n, int fmt, uint32_t* d_out, hipStream_t st) {
   if (n == 0) return 0;
@@ -2052,12 +2061,7 @@ int verify_msm_common(int curve, const uint64_t* a_gens_xyz, const uint64_t* b_g
   Ctx& C = cx();
   const bool from_device = d_q != nullptr;
   bool piped = false;  // a chunked generator upload is in flight
-  struct PipeGuard {   // the caller's arrays are read until pt_upload_end returns: on every path out of here
-    bool& on;
-    ~PipeGuard() {
-      if (on) (void)pt_upload_end();
-    }
-  } pipe_guard{piped};
+  PipeGuard pipe_guard{piped};
   if (k > 30) return fail(BPGPU_E_ARG, "too many rounds");
   const size_t np = (size_t)1 << k;
   if (pow2_at_least(n < 1 ? 1 : n) != np) return fail(BPGPU_E_ARG, "proof has %zu rounds but the generators need %zu elements", k, n);
@@ -2360,13 +2364,23 @@ int bpgpu_kary_cross_terms(int curve, const uint64_t* a_gens_xyz, const uint64_t
   uint32_t* dp = C.st_pts.as<uint32_t>();
   uint32_t* ds = C.st_sc.as<uint32_t>();
   hipStream_t st = C.stream;
+  bool piped = false;  // the generators' chunked upload is in flight
+  PipeGuard pipe_guard{piped};
+  TRY(upload_points(curve, ip_gen_xyz, 1, 0, dp + 32 * N, st));
   if (N) {
     HIP_TRY(upload_async(ds, a, N * 32, st));
     HIP_TRY(upload_async(ds + 8 * N, b, N * 32, st));
-    TRY(upload_points(curve, a_gens_xyz, N, 0, dp, st));
-    TRY(upload_points(curve, b_gens_xyz, N, 0, dp + 16 * N, st));
+    if (N * 96 >= Uploader::MIN_BYTES) {
+      // the generators cross PCIe while the inner products and the first batch's sort run on the scalars: that batch's
+      // accumulation is what waits for the last chunk
+      PtSeg segs[2] = {{a_gens_xyz, N, 0, dp, 0}, {b_gens_xyz, N, 0, dp + 16 * N, 0}};
+      TRY(pt_upload_begin(curve, segs, 2, st));
+      piped = true;
+    } else {
+      TRY(upload_points(curve, a_gens_xyz, N, 0, dp, st));
+      TRY(upload_points(curve, b_gens_xyz, N, 0, dp + 16 * N, st));
+    }
   }
-  TRY(upload_points(curve, ip_gen_xyz, 1, 0, dp + 32 * N, st));
   // the 2 (k - 1) summed inner products, two per launch
   for (size_t t = 0; t + 1 < k; t++) {
     const uint32_t off = (uint32_t)((t + 1) * ck), m = Nu - off;
@@ -2390,7 +2404,16 @@ int bpgpu_kary_cross_terms(int curve, const uint64_t* a_gens_xyz, const uint64_t
       plan.seg[2 * i + 1][1] = MsmSeg{Nu, Nu + off, m};
       plan.seg[2 * i + 1][2] = MsmSeg{2 * Nu, (uint32_t)(2 * N + 2 * t + 1), 1};
     }
-    TRY(msm_dispatch(curve, dp, ds, plan, out));
+    if (piped) {
+      const std::function<int()> ready = [&]() -> int { return pt_upload_wait(0, st); };
+      const int rc = msm_dispatch(curve, dp, ds, plan, out, &ready);
+      piped = false;
+      const int rc_up = pt_upload_end();
+      TRY(rc);
+      TRY(rc_up);
+    } else {
+      TRY(msm_dispatch(curve, dp, ds, plan, out));
+    }
     for (size_t i = 0; i < cnt; i++) {
       memcpy(pos_xy_inf + 9 * (t0 + i), out[2 * i], 72);
       memcpy(neg_xy_inf + 9 * (t0 + i), out[2 * i + 1], 72);

@@ -215,3 +215,21 @@ def test_kary_cross_terms_batched(ffi, c, n, k):
     # k = 1: no cross terms, nothing written
     p1, n1 = ffi.kary_cross_terms(cid, A, B, q, a, b, 1)
     assert p1.shape == (0, 9) and n1.shape == (0, 9)
+
+
+def test_kary_cross_terms_piped_upload(ffi):
+    """Generators of 8 MiB and more go up in chunks while the inner products and the batch's sort run (the accumulation
+    waits for the last chunk): n = 3 * 2^15, k = 3, one generator with Z = 3 (its chunk goes up as Jacobian rows),
+    against the reference's recipe of k (k - 1) separate MSMs."""
+    from bulletproofs_amd import ark_bp
+    c, cid, n, k = pm.PALLAS, 0, 3 << 15, 3
+    A, B, q, a, b, _ = ark_bp.ipa_inputs(cid, n)
+    B = B.copy()
+    xb, yb = H.jac_from_abi(c, B[70_000:70_001])[0]
+    B[70_000] = H.jac_abi(c, [(xb * 9 % c.q, yb * 27 % c.q, 3)])[0]
+    Bn = B.copy()
+    Bn[70_000] = H.jac_abi(c, [(xb, yb)])[0]
+    pos, neg = ffi.kary_cross_terms(cid, A, B, q, a, b, k)
+    want_pos, want_neg = _cross_terms_by_the_reference_recipe(c, cid, A, Bn, q.reshape(12), a, b, k)
+    assert [H.xy_inf_to_affine(c, p) for p in pos] == want_pos
+    assert [H.xy_inf_to_affine(c, p) for p in neg] == want_neg
