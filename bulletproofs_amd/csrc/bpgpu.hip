@@ -2008,8 +2008,7 @@ int bpgpu_fold_points(int curve, const uint64_t* g_xyz, size_t n_out, const uint
   size_t n2 = 2 * n_out;
   TRY(cx().st_pts_in.ensure(n2 * 96));
   TRY(cx().st_pts.ensure(n2 * 64));
-  HIP_TRY(upload_async(cx().st_pts_in.p, g_xyz, n2 * 96, cx().stream));
-  TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), cx().st_pts.as<uint32_t>(), n2, 0));
+  TRY(upload_points(curve, g_xyz, n2, 0, cx().st_pts.as<uint32_t>(), cx().stream));  // chunked, Z = 1 rows compacted
   uint32_t* d = cx().st_pts.as<uint32_t>();
   TRY(fold_points_launch(curve, d, d, s_lo, s_hi, d, d, s_lo, s_hi, 1, (uint32_t)n_out));
   TRY(points_out(curve, d, cx().st_pts_in.as<uint32_t>(), n_out));
@@ -2325,8 +2324,7 @@ int bpgpu_fold_points_kary(int curve, const uint64_t* g_xyz, size_t ck, size_t k
   uint32_t* d = cx().st_pts.as<uint32_t>();
   uint32_t* d_o = d + 16ull * tot;
   if (tot) {
-    HIP_TRY(upload_async(cx().st_pts_in.p, g_xyz, tot * 96, cx().stream));
-    TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), d, tot, 0));
+    TRY(upload_points(curve, g_xyz, tot, 0, d, cx().stream));  // chunked, Z = 1 rows compacted
   }
   TRY(fold_points_kary_launch(curve, d, ck, k, y, d_o));
   TRY(points_out(curve, d_o, cx().st_pts_in.as<uint32_t>(), ck));
@@ -2456,10 +2454,9 @@ int bpgpu_hadamard_points(int curve, const uint64_t* bases_xyz, const uint64_t* 
   TRY(cx().st_pts_in.ensure(n * 96));
   TRY(cx().st_pts.ensure(n * 64));
   TRY(cx().st_sc.ensure(n * 32));
-  HIP_TRY(upload_async(cx().st_pts_in.p, bases_xyz, n * 96, cx().stream));
   HIP_TRY(upload_async(cx().st_sc.p, scalars, n * 32, cx().stream));
   uint32_t* d = cx().st_pts.as<uint32_t>();
-  TRY(points_in(curve, cx().st_pts_in.as<uint32_t>(), d, n, 0));
+  TRY(upload_points(curve, bases_xyz, n, 0, d, cx().stream));  // chunked, Z = 1 rows compacted
   {
     OpSpan span(cx());
     if (curve == BPGPU_PALLAS)
